@@ -1,0 +1,210 @@
+"""ctypes wrapper around oracle/libstepth_oracle.so -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module;
+the product package (stepth_amd/) must never do so.  See oracle/stepth_oracle.h for what is
+restated from which reference lines and for the parity status.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Optional, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libstepth_oracle.so")
+
+SERIAL, REF8, ALLCORES = 0, 1, 2
+OK, ERR_BAD_ARG, ERR_MAX_ZERO = 0, -1, -4
+
+
+class Group(C.Structure):
+    _fields_ = [("x", C.c_uint32), ("y", C.c_uint32), ("w", C.c_uint32), ("h", C.c_uint32),
+                ("value", C.c_uint8 * 3), ("pad", C.c_uint8)]
+
+
+GROUP_DTYPE = np.dtype([("x", "<u4"), ("y", "<u4"), ("w", "<u4"), ("h", "<u4"),
+                        ("value", "u1", (3,)), ("pad", "u1")])
+assert GROUP_DTYPE.itemsize == C.sizeof(Group) == 20
+
+
+def build(force: bool = False, lib_path: str = _LIB_PATH, march: Optional[str] = None) -> str:
+    """Compile the oracle with gcc (plain C, no GPU)."""
+    src = os.path.join(_HERE, "stepth_oracle.c")
+    if (not force and os.path.exists(lib_path)
+            and os.path.getmtime(lib_path) >= max(os.path.getmtime(src),
+                                                  os.path.getmtime(src[:-2] + ".h"))):
+        return lib_path
+    cmd = ["gcc", "-O3", f"-march={march or 'x86-64-v2'}", "-fPIC", "-Wall", "-Wextra",
+           "-std=c11", "-D_POSIX_C_SOURCE=200809L", src, "-o", lib_path, "-shared", "-lm",
+           "-lpthread"]
+    subprocess.run(cmd, check=True)
+    return lib_path
+
+
+_lib = None
+
+
+def lib(path: Optional[str] = None):
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or _LIB_PATH
+    if not os.path.exists(p):
+        build(lib_path=p)
+    L = C.CDLL(p)
+    u8p, u32p, u64p = C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
+    L.oracle_distance_dot_dot.restype = C.c_uint32
+    L.oracle_distance_dot_dot.argtypes = [C.c_uint32] * 4
+    L.oracle_distance_dot_array.restype = C.c_int
+    L.oracle_distance_dot_array.argtypes = [u8p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_size_t,
+                                            C.c_uint32, C.c_uint32, C.c_uint32, u8p, u32p, u32p,
+                                            u32p, u64p, u64p]
+    L.oracle_uniform_groups.restype = C.c_size_t
+    L.oracle_uniform_groups.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_size_t,
+                                        C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+    L.oracle_match_groups.restype = C.c_int
+    L.oracle_match_groups.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint32, C.c_uint32,
+                                      C.c_size_t, C.c_uint32, u8p, C.c_int, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, u64p]
+    L.oracle_normalise.restype = C.c_int
+    L.oracle_normalise.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, u8p]
+    L.oracle_paint.restype = None
+    L.oracle_paint.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32,
+                               C.c_void_p, C.c_size_t]
+    L.oracle_depth_from_additional.restype = C.c_int
+    L.oracle_depth_from_additional.argtypes = [
+        C.c_void_p, C.c_uint32, C.c_uint32, C.c_size_t, C.c_uint32, C.c_void_p, C.c_uint32,
+        C.c_uint32, C.c_size_t, u8p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t,
+        C.c_int, C.c_void_p, C.c_void_p, u8p, u64p]
+    L.oracle_sad_rows.restype = C.c_int
+    L.oracle_sad_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_size_t,
+                                  C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, u8p,
+                                  C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
+    L.oracle_hardware_threads.restype = C.c_int
+    if path is None:
+        _lib = L
+    return L
+
+
+def _u8x3(v):
+    return (C.c_uint8 * 3)(*[int(x) for x in v])
+
+
+def _img(a: np.ndarray, channels=(3,)) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    assert a.ndim == 3 and a.shape[2] in channels, a.shape
+    return a
+
+
+def distance_dot_dot(f: Tuple[int, int], s: Tuple[int, int]) -> int:
+    return int(lib().oracle_distance_dot_dot(f[0], f[1], s[0], s[1]))
+
+
+def distance_dot_array(what, array: np.ndarray, from_xy: Tuple[int, int], max_steps: int,
+                       precision, count: bool = False):
+    """helpers::distance_dot_array -> None or (distance, (x, y)) [, probes, cells]."""
+    array = _img(array)
+    ah, aw = array.shape[:2]
+    d, px, py = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+    probes, cells = C.c_uint64(0), C.c_uint64(0)
+    found = lib().oracle_distance_dot_array(
+        _u8x3(what), array.ctypes.data, aw, ah, array.strides[0], from_xy[0], from_xy[1],
+        max_steps, _u8x3(precision), C.byref(d), C.byref(px), C.byref(py), C.byref(probes),
+        C.byref(cells))
+    res = (int(d.value), (int(px.value), int(py.value))) if found else None
+    if count:
+        return res, int(probes.value), int(cells.value)
+    return res
+
+
+def uniform_groups(main: np.ndarray, tile_w: int, tile_h: int) -> np.ndarray:
+    main = _img(main, (3, 4))
+    h, w, ch = main.shape
+    n = lib().oracle_uniform_groups(main.ctypes.data, w, h, main.strides[0], ch, tile_w, tile_h,
+                                    None)
+    groups = np.zeros(n, dtype=GROUP_DTYPE)
+    lib().oracle_uniform_groups(main.ctypes.data, w, h, main.strides[0], ch, tile_w, tile_h,
+                                groups.ctypes.data)
+    return groups
+
+
+def match_groups(groups: np.ndarray, add: np.ndarray, max_steps: int, precision,
+                 threads: int = ALLCORES):
+    """PASS 1 -> dict(raw u8 [n], raw32 u32 [n], pos [n,2], found [n], probes)."""
+    add = _img(add)
+    groups = np.ascontiguousarray(groups, dtype=GROUP_DTYPE)
+    ah, aw = add.shape[:2]
+    raw = np.zeros(len(groups), np.uint8)
+    raw32 = np.zeros(len(groups), np.uint32)
+    pos = np.zeros((len(groups), 2), np.uint32)
+    found = np.zeros(len(groups), np.uint8)
+    probes = C.c_uint64(0)
+    rc = lib().oracle_match_groups(groups.ctypes.data, len(groups), add.ctypes.data, aw, ah,
+                                   add.strides[0], max_steps, _u8x3(precision), threads,
+                                   raw.ctypes.data, raw32.ctypes.data, pos.ctypes.data,
+                                   found.ctypes.data, C.byref(probes))
+    assert rc == OK, rc
+    return {"raw": raw, "raw32": raw32, "pos": pos, "found": found,
+            "probes": int(probes.value)}
+
+
+def normalise(raw: np.ndarray):
+    raw = np.ascontiguousarray(raw, dtype=np.uint8).ravel()
+    out = np.zeros_like(raw)
+    mx = C.c_uint8(0)
+    rc = lib().oracle_normalise(raw.ctypes.data, raw.size, out.ctypes.data, C.byref(mx))
+    return rc, out, int(mx.value)
+
+
+def paint(groups: np.ndarray, values: np.ndarray, w: int, h: int) -> np.ndarray:
+    groups = np.ascontiguousarray(groups, dtype=GROUP_DTYPE)
+    values = np.ascontiguousarray(values, dtype=np.uint8)
+    depth = np.zeros((h, w), np.uint8)
+    lib().oracle_paint(groups.ctypes.data, values.ctypes.data, len(groups), w, h,
+                       depth.ctypes.data, w)
+    return depth
+
+
+def depth_from_additional(main: np.ndarray, add: np.ndarray, precision, max_steps: int = 255,
+                          tile: Tuple[int, int] = (1, 1), groups: Optional[np.ndarray] = None,
+                          threads: int = ALLCORES):
+    """Whole path (no Gaussian tail) -> dict(status, depth, raw, max, probes)."""
+    main = _img(main, (3, 4))
+    add = _img(add)
+    h, w, ch = main.shape
+    ah, aw = add.shape[:2]
+    depth = np.zeros((h, w), np.uint8)
+    raw = np.zeros((h, w), np.uint8)
+    mx, probes = C.c_uint8(0), C.c_uint64(0)
+    gptr, gn = None, 0
+    if groups is not None:
+        groups = np.ascontiguousarray(groups, dtype=GROUP_DTYPE)
+        gptr, gn = groups.ctypes.data, len(groups)
+    rc = lib().oracle_depth_from_additional(
+        main.ctypes.data, w, h, main.strides[0], ch, add.ctypes.data, aw, ah, add.strides[0],
+        _u8x3(precision), max_steps, tile[0], tile[1], gptr, gn, threads, depth.ctypes.data,
+        raw.ctypes.data, C.byref(mx), C.byref(probes))
+    return {"status": rc, "depth": depth, "raw": raw, "max": int(mx.value),
+            "probes": int(probes.value)}
+
+
+def sad_rows(left: np.ndarray, right: np.ndarray, d_max: int, win: int, precision,
+             row0: int = 0, row1: Optional[int] = None, threads: int = ALLCORES) -> np.ndarray:
+    left = _img(left, (3, 4))
+    right = _img(right)
+    h, w, ch = left.shape
+    assert right.shape[:2] == (h, w)
+    row1 = h if row1 is None else row1
+    raw = np.zeros((h, w), np.uint8)
+    rc = lib().oracle_sad_rows(left.ctypes.data, right.ctypes.data, w, h, left.strides[0],
+                               right.strides[0], ch, d_max, win, _u8x3(precision), row0, row1,
+                               threads, raw.ctypes.data)
+    assert rc == OK, rc
+    return raw
+
+
+def hardware_threads() -> int:
+    return int(lib().oracle_hardware_threads())

@@ -1,0 +1,114 @@
+/*
+ * stepth_oracle.h -- CPU restatement of nikilark/stepth's open_depth_from_additional path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under stepth_amd/ (the product) may include, link or
+ * call this.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it,
+ * and there only as the checker / the timed CPU baseline ("kind": "port").
+ *
+ * This is a C restatement of Rust code, NOT the Rust binary: the reference cannot be built in
+ * this environment (no rustc/cargo; nightly feature gate at src/lib.rs:1; the `disage`
+ * dependency is an empty, un-vendored submodule, .gitmodules:1-3 / Cargo.toml:9).
+ *
+ * Parity status (see DESIGN.md "Oracle"):
+ *   - ring first-hit matcher, middle, u8 wrap, max, normalise: restated line by line from
+ *     src/helpers.rs:3-54 and src/depth_image.rs:111-129; pinned by tolerance against the
+ *     reference's only shipped result, assets/depth.jpg (tests/test_oracle_asset.py).
+ *   - disage::PixelOpps::{substract,lt} (source absent): per-channel |a-b| and ALL channels
+ *     strictly `<`, pinned empirically by the same asset.
+ *   - disage grouping (rgb_discrete), to_luma8_from_rgb8 and image 0.23.14's Gaussian
+ *     resample: source absent, no fixture -> "parity unpinned"; groups are an explicit input
+ *     here (uniform tiles or a caller-supplied rectangle list).
+ *   - the windowed-SAD mode has no counterpart in the reference at all (self-oracle).
+ *
+ * All citations are relative to /root/reference.
+ */
+#ifndef STEPTH_ORACLE_H
+#define STEPTH_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Mirrors disage::DiscretePixel{position{x,y}, size{width,height}, value:[u8;3]} as used at
+ * src/depth_image.rs:110-121.  Same layout as stepth_group in include/stepth_amd.h. */
+typedef struct {
+    uint32_t x, y, w, h;
+    uint8_t value[3];
+    uint8_t pad;
+} oracle_group;
+
+enum {
+    ORACLE_OK = 0,
+    ORACLE_ERR_BAD_ARG = -1,
+    ORACLE_ERR_MAX_ZERO = -4 /* src/depth_image.rs:127 divides by max; the reference panics */
+};
+
+enum { ORACLE_THREADS_SERIAL = 0, ORACLE_THREADS_REF8 = 1, ORACLE_THREADS_ALLCORES = 2 };
+
+/* src/helpers.rs:3-7 -- (((x1-x2)^2 + (y1-y2)^2) as f64).sqrt() as u32 */
+uint32_t oracle_distance_dot_dot(uint32_t fx, uint32_t fy, uint32_t sx, uint32_t sy);
+
+/* src/helpers.rs:9-54.  `array` is the additional image as row-major RGB8, indexed [y][x]
+ * (helpers.rs:31-32), `stride` bytes per row.  Returns 1 and fills dist/pos on a hit, 0 for
+ * None.  `probes`, when non-NULL, is incremented once per predicate evaluation (in-bounds
+ * cell), `cells` once per get2d call. */
+int oracle_distance_dot_array(const uint8_t what[3], const uint8_t *array, uint32_t aw,
+                              uint32_t ah, size_t stride, uint32_t from_x, uint32_t from_y,
+                              uint32_t max, const uint8_t precision[3], uint32_t *dist,
+                              uint32_t *pos_x, uint32_t *pos_y, uint64_t *probes,
+                              uint64_t *cells);
+
+/* Uniform-tile stand-in for disage::open::rgb_discrete (src/depth_image.rs:104-110):
+ * tiles of tile_w x tile_h (edge tiles clipped), row-major order, value = per-channel
+ * floor(mean).  tile 1x1 -> value is the pixel itself.  Returns the number of groups
+ * written (or needed, when groups == NULL).  `main_px` has `channels` (3 or 4) bytes per
+ * pixel; alpha is dropped like DynamicImage::to_rgb8 (src/depth_image.rs:105). */
+size_t oracle_uniform_groups(const uint8_t *main_px, uint32_t w, uint32_t h, size_t stride,
+                             uint32_t channels, uint32_t tile_w, uint32_t tile_h,
+                             oracle_group *groups);
+
+/* PASS 1 of src/depth_image.rs:112-123 over groups [0,n): raw[i] = (d as u8), d = 0 on None.
+ * Optional outputs: raw_u32 (d before the cast), pos_xy (winning cell, 2 per group), found.
+ * threads: ORACLE_THREADS_*; REF8 reproduces par_chunks_mut(len/8) (depth_image.rs:111-112). */
+int oracle_match_groups(const oracle_group *groups, size_t n, const uint8_t *add_px,
+                        uint32_t aw, uint32_t ah, size_t astride, uint32_t max_steps,
+                        const uint8_t precision[3], int threads, uint8_t *raw,
+                        uint32_t *raw_u32, uint32_t *pos_xy, uint8_t *found, uint64_t *probes);
+
+/* src/depth_image.rs:124-129: max over raw, then raw*255/max in u64 (floor).
+ * Returns ORACLE_ERR_MAX_ZERO (and zero-fills out) when max == 0. */
+int oracle_normalise(const uint8_t *raw, size_t n, uint8_t *out, uint8_t *max_out);
+
+/* discr_main.collect() + to_luma8 (src/depth_image.rs:130-132) without the Gaussian tail:
+ * paints each group's value over its rectangle into depth[H][W]. */
+void oracle_paint(const oracle_group *groups, const uint8_t *values, size_t n, uint32_t w,
+                  uint32_t h, uint8_t *depth, size_t dstride);
+
+/* Whole path, src/depth_image.rs:96-132 (no Gaussian resample).  groups==NULL -> uniform
+ * tiles.  depth is [H][W] u8.  raw_out (optional) receives the painted pre-normalise map. */
+int oracle_depth_from_additional(const uint8_t *main_px, uint32_t w, uint32_t h, size_t mstride,
+                                 uint32_t mchannels, const uint8_t *add_px, uint32_t aw,
+                                 uint32_t ah, size_t astride, const uint8_t precision[3],
+                                 uint32_t max_steps, uint32_t tile_w, uint32_t tile_h,
+                                 const oracle_group *groups, size_t n_groups, int threads,
+                                 uint8_t *depth, uint8_t *raw_out, uint8_t *max_out,
+                                 uint64_t *probes);
+
+/* Windowed-SAD mode (north_star's literal description; NOT in the reference; self-oracle).
+ * cost(x,y,d) = sum over win x win window, 3 channels of |L(x+i,y+j) - R(x+i-d,y+j)| with
+ * clamp-to-edge coordinates; raw = smallest d in [0,d_max) with cost < win*win*(p0+p1+p2),
+ * else the argmin (smallest d on ties).  Rows [row0,row1). */
+int oracle_sad_rows(const uint8_t *left, const uint8_t *right, uint32_t w, uint32_t h,
+                    size_t lstride, size_t rstride, uint32_t channels, uint32_t d_max,
+                    uint32_t win, const uint8_t precision[3], uint32_t row0, uint32_t row1,
+                    int threads, uint8_t *raw);
+
+int oracle_hardware_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
