@@ -1,0 +1,243 @@
+#!/usr/bin/env python3
+"""bench.py -- Mpixels/s of depth output for stepth's open_depth_from_additional hot path.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 launched under
+torch.distributed.run, one rank per GPU.  Rank 0 prints ONE JSON line.
+
+Workload (BASELINE.json metric: "Mpixels/sec depth output, 1080p stereo d_max=128"):
+  a step = one pass of the hot path over a batch of `frames_per_gpu * N` synthetic 1920x1080
+  stereo pairs (inputs resident in HBM), reference-exact mode (square-ring first hit,
+  /root/reference/src/helpers.rs:9-54), one group per pixel, max_steps = d_max = 128,
+  precision [36;3] (Readme.md:14).  Per frame: pack additional -> ring_match -> max ->
+  normalise -> depth rows.  With N > 1 every frame is sharded by row strips over the N ranks,
+  with one all_reduce(MAX) and one all_gather of depth rows per step (RCCL); per-GPU work is
+  constant in N (weak scaling).  value = frames * 1920*1080 / step time, whole job.
+
+  --mode sad runs the windowed-SAD mode (5x5, d_max=128) instead; it has no counterpart in the
+  reference and is reported under its own metric name.
+
+roofline: HBM-bound by contract (scan/compare, no MFMA).  achieved = algorithmic bytes per
+  ring_match launch (7 B per output pixel: 3 B main RGB + 3 B additional RGB + 1 B depth,
+  SURVEY.md 8d) / that kernel's mean launch time, measured live with HIP events on the
+  engine's stream; peak = 8 TB/s.  The ring search is data dependent, so the mean number of
+  probes per pixel is printed next to it.
+cpu_baseline: the C restatement of the reference algorithm (oracle/, "port" -- NOT the Rust
+  binary) on one frame of the same workload, all host cores with dynamic scheduling, plus the
+  reference's own static 8-chunk partition (src/depth_image.rs:111-112) as `ref8_value`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
+ALGO_BYTES_PER_PIXEL = 7.0
+
+
+def make_frames(width, height, d_max, count):
+    """`count` distinct synthetic pairs from two seeded base pairs and their flips."""
+    from stepth_amd import synth
+    bases = [synth.stereo_pair(width, height, d_max, seed=0x5EED + i)[:2]
+             for i in range(min(2, count))]
+    flips = [lambda a: a, lambda a: a[:, ::-1], lambda a: a[::-1], lambda a: a[::-1, ::-1]]
+    frames = []
+    for i in range(count):
+        l, r = bases[i % len(bases)]
+        f = flips[(i // len(bases)) % 4]
+        frames.append((np.ascontiguousarray(f(l)), np.ascontiguousarray(f(r))))
+    return frames
+
+
+def cpu_baseline(frame, args):
+    """Times the oracle (test infrastructure; allowed here as the CPU baseline) on one frame."""
+    from oracle import oracle as O
+    try:  # a host-tuned build of the same C file, kept out of the tree
+        lib_path = O.build(force=True, lib_path=os.path.join("/tmp", f"stepth_oracle_native_{os.getpid()}.so"),
+                           march="native")
+        O._lib = O.lib(lib_path)
+    except Exception:
+        O.lib()
+    l, r = frame
+    prec = [args.precision] * 3
+    if args.mode == "ring":
+        t0 = time.perf_counter()
+        ref = O.depth_from_additional(l, r, prec, args.d_max, (1, 1), threads=O.ALLCORES)
+        t_all = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        O.depth_from_additional(l, r, prec, args.d_max, (1, 1), threads=O.REF8)
+        t_ref8 = time.perf_counter() - t0
+        px = l.shape[0] * l.shape[1]
+        out = {"value": round(px / t_all / 1e6, 4), "unit": "Mpixels/s",
+               "cores": O.hardware_threads(), "kind": "port",
+               "sample": f"1 frame {l.shape[1]}x{l.shape[0]}, all cores, dynamic schedule; "
+                         "C restatement of the reference algorithm, not the Rust binary",
+               "seconds": round(t_all, 3),
+               "ref8_value": round(px / t_ref8 / 1e6, 4),
+               "ref8_note": "static len/8 chunks like src/depth_image.rs:111-112 (9 threads max)",
+               "probes_per_pixel": round(ref["probes"] / px, 1)}
+        return out, ref["depth"]
+    rows = min(l.shape[0], 32)  # SAD on CPU is ~1e3x slower: a 32-row band
+    t0 = time.perf_counter()
+    raw = O.sad_rows(l, r, args.d_max, args.win, prec, 0, rows, threads=O.ALLCORES)
+    t_all = time.perf_counter() - t0
+    out = {"value": round(rows * l.shape[1] / t_all / 1e6, 4), "unit": "Mpixels/s",
+           "cores": O.hardware_threads(), "kind": "port",
+           "sample": f"rows 0..{rows} of 1 frame {l.shape[1]}x{l.shape[0]}, all cores",
+           "seconds": round(t_all, 3)}
+    return out, raw[:rows]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--mode", choices=["ring", "sad"], default="ring")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--d-max", dest="d_max", type=int, default=128)
+    ap.add_argument("--win", type=int, default=5)
+    ap.add_argument("--precision", type=int, default=36)
+    ap.add_argument("--frames-per-gpu", dest="fpg", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run "
+                     "(--nproc-per-node N)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from stepth_amd import MODE_RING_FIRST_HIT, MODE_SAD_WINDOW, Engine
+    from stepth_amd.sharding import EngineStripWorker, sharded_depth, strip_bounds
+
+    W, H = args.width, args.height
+    n_frames = args.fpg * world
+    frames_np = make_frames(W, H, args.d_max, n_frames)
+    frames = [(torch.from_numpy(l).to(dev), torch.from_numpy(r).to(dev)) for l, r in frames_np]
+
+    eng = Engine(local_rank)
+    eng.use_torch_stream()
+    prec = [args.precision] * 3
+    if args.mode == "ring":
+        worker = EngineStripWorker(eng, prec, max_steps=args.d_max, tile=(1, 1),
+                                   mode=MODE_RING_FIRST_HIT)
+    else:
+        worker = EngineStripWorker(eng, prec, mode=MODE_SAD_WINDOW, d_max=args.d_max, win=args.win)
+
+    def step():
+        return sharded_depth(worker, frames, H, W)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    depth = None
+    for _ in range(args.warmup):
+        depth, _mx = step()
+    fence()
+    eng.kernel_time_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        depth, _mx = step()
+    fence()
+    dt = time.perf_counter() - t0
+    kms, klaunches = eng.kernel_time_read()
+    eng.kernel_time_enable(False)
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+
+    # probes/pixel of this rank's strips (data-dependent work), outside the timed region
+    probes_pp = None
+    if args.mode == "ring":
+        r0, r1 = strip_bounds(H, world)[rank]
+        eng.stats_enable(True)
+        tot_p = tot_g = 0
+        for f in frames[: min(len(frames), 8)]:
+            worker.match_strip(f, (r0, r1))
+            s = eng.stats()
+            tot_p += s["probes"]
+            tot_g += s["groups"]
+        eng.stats_enable(False)
+        probes_pp = tot_p / max(tot_g, 1)
+
+    if rank == 0:
+        px_step = n_frames * W * H
+        value = px_step * args.steps / dt / 1e6
+        strip_rows = strip_bounds(H, world)[0]
+        px_launch = (strip_rows[1] - strip_rows[0]) * W
+        k_avg_ms = kms / max(klaunches, 1)
+        achieved = ALGO_BYTES_PER_PIXEL * px_launch / (k_avg_ms * 1e-3) / 1e9 if klaunches else 0.0
+        out = {
+            "metric": ("Mpixels/sec depth output, 1080p stereo d_max=128" if args.mode == "ring"
+                       else "Mpixels/sec depth output, windowed-SAD mode (not in the reference)"),
+            "value": round(value, 3), "unit": "Mpixels/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic (seeded value-noise stereo pairs + flips, "
+                                   "stepth_amd/synth.py); inputs resident in HBM",
+            "config": {
+                "workload": (f"{n_frames} x {W}x{H} synthetic stereo pairs per step "
+                             f"({args.fpg} per GPU), "
+                             + (f"ring first-hit (reference-exact), 1x1 groups, max_steps=d_max={args.d_max}"
+                                if args.mode == "ring" else
+                                f"windowed SAD {args.win}x{args.win}, d_max={args.d_max}")
+                             + f", precision [{args.precision};3]"),
+                "frames_per_step": n_frames, "width": W, "height": H, "d_max": args.d_max,
+                "mode": args.mode,
+                "parallelism": (f"row strips x{world} + all_reduce(max) + all_gather (RCCL)"
+                                if world > 1 else "single GPU"),
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                "kernel": "ring_match_kernel" if args.mode == "ring" else "sad_match_kernel",
+                "kernel_avg_ms": round(k_avg_ms, 4), "kernel_launches": klaunches,
+                "algorithmic_bytes_per_launch": ALGO_BYTES_PER_PIXEL * px_launch,
+                "probes_per_pixel": None if probes_pp is None else round(probes_pp, 1),
+            },
+        }
+        if not args.no_cpu_baseline:
+            base, ref_depth = cpu_baseline(frames_np[0], args)
+            out["cpu_baseline"] = base
+            got = depth[0].cpu().numpy()
+            if args.mode == "ring":
+                out["parity_frame0_bit_exact"] = bool(np.array_equal(got, ref_depth))
+            else:
+                mx = int(_mx[0].item())
+                exp = (ref_depth.astype(np.uint32) * 255 // max(mx, 1)).astype(np.uint8)
+                out["parity_frame0_bit_exact"] = bool(np.array_equal(got[: exp.shape[0]], exp))
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,177 @@
+/*
+ * stepth_amd.h -- C-ABI of the MI355X (gfx950) engine for stepth's
+ * DepthImage::open_depth_from_additional hot path.
+ *
+ * The reference (nikilark/stepth, Rust) has no FFI, plugin or operator interface: the
+ * boundary is its own method DepthImage::load_depth_from_additional
+ * (/root/reference/src/depth_image.rs:91-136).  The entry points below are what a Rust
+ * `extern "C"` block for that method would bind (stub: INTEGRATION.md); each comment cites
+ * the reference lines the call replaces.  Plain pointers and sizes only; no C++/torch types.
+ *
+ * Conventions
+ *  - Every call returns a stepth_status (0 = ok, negative = error) and never throws/aborts.
+ *    stepth_last_error(engine) gives the message of the last failing call on that engine.
+ *  - All image memory is caller-owned and only borrowed: the engine never frees it and does
+ *    not keep pointers past the return of a synchronous call, or past stepth_engine_sync()
+ *    for calls made with STEPTH_FLAG_ASYNC.
+ *  - Images are row-major, 8-bit, `stride` bytes per row (>= width*channels), `memory` says
+ *    whether `data` is a host pointer or a device (HIP) pointer on the engine's device.
+ *  - An engine is bound to one device and one stream and is NOT thread-safe; different
+ *    engines may be used from different threads concurrently (the reference's &mut self
+ *    exclusivity, src/depth_image.rs:91-92).
+ */
+#ifndef STEPTH_AMD_H
+#define STEPTH_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STEPTH_ABI_VERSION 1u
+
+typedef struct stepth_engine stepth_engine; /* opaque */
+
+typedef enum {
+    STEPTH_OK = 0,
+    STEPTH_ERR_BAD_ARG = -1,
+    /* "Sizes don't match", src/depth_image.rs:37-49 (load_depth's check) */
+    STEPTH_ERR_SIZE_MISMATCH = -2,
+    STEPTH_ERR_HIP = -3,
+    /* every group's distance was 0: the reference divides by max and panics
+     * (src/depth_image.rs:127); here the output is all zero and this status is returned */
+    STEPTH_ERR_MAX_ZERO = -4,
+    STEPTH_ERR_NO_DEVICE = -5,
+    STEPTH_ERR_OUT_OF_MEMORY = -6
+} stepth_status;
+
+typedef enum {
+    /* reference-exact: square-ring first-hit search, src/helpers.rs:9-54 */
+    STEPTH_MODE_RING_FIRST_HIT = 0,
+    /* horizontal-disparity windowed SAD (BASELINE north_star's wording; not in the
+     * reference, checked against the engine's own CPU statement only) */
+    STEPTH_MODE_SAD_WINDOW = 1
+} stepth_mode;
+
+typedef enum { STEPTH_MEM_HOST = 0, STEPTH_MEM_DEVICE = 1 } stepth_memory;
+
+enum {
+    /* enqueue on the engine's stream and return without synchronising; every pointer must
+     * then be device memory and STEPTH_ERR_MAX_ZERO is not reported (output is all zero) */
+    STEPTH_FLAG_ASYNC = 1u << 0,
+    /* stop after PASS 1 (src/depth_image.rs:112-123): write the painted, un-normalised
+     * (d as u8) map; used by row-strip sharding, where the max is reduced across ranks
+     * before stepth_normalise_rows() */
+    STEPTH_FLAG_RAW_ONLY = 1u << 1
+};
+
+/* disage::DiscretePixel{position{x,y}, size{width,height}, value:[u8;3]} as consumed at
+ * src/depth_image.rs:110-121.  20 bytes, little-endian, no padding surprises. */
+typedef struct {
+    uint32_t x, y, w, h;
+    uint8_t value[3];
+    uint8_t pad;
+} stepth_group;
+
+typedef struct {
+    const void *data;
+    uint32_t width, height;
+    uint32_t channels; /* main: 3 (RGB) or 4 (RGBA as stored in DepthImage.image,
+                          src/depth_image.rs:8; alpha ignored like to_rgb8 at :105);
+                          additional: 3; depth output: 1 */
+    uint32_t memory;   /* stepth_memory */
+    size_t stride;     /* bytes per row */
+} stepth_image;
+
+typedef struct {
+    uint32_t struct_size;  /* sizeof(stepth_params), for forward compatibility */
+    uint32_t mode;         /* stepth_mode */
+    uint8_t precision[3];  /* src/depth_image.rs:79 */
+    uint8_t reserved0;
+    uint32_t max_steps;    /* ring mode: `max` of helpers.rs:13; the reference passes 255
+                              (src/depth_image.rs:119) */
+    uint32_t tile_w, tile_h; /* ring mode, groups == NULL: uniform tiles, value = floor(mean);
+                                1x1 = one group per pixel */
+    uint32_t d_max, win;   /* SAD mode: disparities [0,d_max), odd window side */
+    uint32_t row_begin, row_end; /* main-image rows to compute; 0,0 = all.  A group belongs
+                                    to the strip when its top row y is inside it */
+    uint32_t flags;        /* STEPTH_FLAG_* */
+} stepth_params;
+
+/* counters of the last ring-mode call, for "mean probes/pixel" reporting */
+typedef struct {
+    uint64_t groups;       /* groups (queries) processed */
+    uint64_t ring0_hits;   /* groups that matched at their centre cell */
+    uint64_t probes;       /* predicate evaluations issued by the kernels (lane-granular) */
+} stepth_stats;
+
+uint32_t stepth_abi_version(void);
+const char *stepth_status_string(int status);
+
+/* One engine per device/stream.  device_id < 0 = current device. */
+int stepth_engine_create(int device_id, stepth_engine **out);
+void stepth_engine_destroy(stepth_engine *engine);
+/* Use the caller's HIP stream (hipStream_t) instead of the engine's own; NULL restores it. */
+int stepth_engine_set_stream(stepth_engine *engine, void *hip_stream);
+int stepth_engine_sync(stepth_engine *engine);
+const char *stepth_last_error(const stepth_engine *engine);
+
+/*
+ * The whole path of DepthImage::load_depth_from_additional up to (not including) the
+ * Gaussian resample: src/depth_image.rs:96-132.
+ *   main        self.image (RGBA8 or RGB8)                       :104-109
+ *   additional  add_image.to_rgb8()                              :96-100
+ *   groups      what disage::open::rgb_discrete would return (:104-110); NULL = uniform
+ *               tiles from params.  `groups_memory` is a stepth_memory.
+ *   depth       [H][W] u8, same width/height as main, else STEPTH_ERR_SIZE_MISMATCH (:37-49)
+ *   max_out     optional; the global max of (d as u8) (:124).  Host pointer for synchronous
+ *               calls, device pointer (uint32_t) with STEPTH_FLAG_ASYNC.
+ */
+int stepth_depth_from_additional(stepth_engine *engine, const stepth_image *main,
+                                 const stepth_image *additional, const stepth_params *params,
+                                 const stepth_group *groups, size_t n_groups,
+                                 uint32_t groups_memory, const stepth_image *depth,
+                                 uint32_t *max_out);
+
+/*
+ * PASS 2 on a strip, src/depth_image.rs:125-129: data[r][c] = data[r][c]*255/max (u64
+ * floor), in place.  `max` is read from `max_ptr` (`max_memory` = host or device) -- after
+ * a cross-rank max reduction in the sharded flow.  max == 0 -> rows are zeroed and
+ * STEPTH_ERR_MAX_ZERO is returned (synchronous calls only).
+ */
+int stepth_normalise_rows(stepth_engine *engine, const stepth_image *rows,
+                          const uint32_t *max_ptr, uint32_t max_memory, uint32_t flags);
+
+/*
+ * helpers::distance_dot_array for a batch of independent queries, src/helpers.rs:9-54:
+ * query i looks for the first cell of `array` (additional image, RGB8) whose per-channel
+ * |cell - what[i]| < precision, scanning square rings around from[i] for max steps.
+ *   what   n x 3 bytes, from_xy n x 2 uint32 (x, y)           (host pointers)
+ *   found  n bytes (1 = Some), dist n uint32 (src/helpers.rs:3-7), pos_xy n x 2 uint32
+ * Exists so that the matcher can be tested in isolation against the oracle.
+ */
+int stepth_distance_dot_array_batch(stepth_engine *engine, const stepth_image *array,
+                                    const uint8_t *what, const uint32_t *from_xy, size_t n,
+                                    uint32_t max, const uint8_t precision[3], uint8_t *found,
+                                    uint32_t *dist, uint32_t *pos_xy);
+
+/* Counting costs a little kernel time, so it is off by default: enable it, run a call, read
+ * the counters of that call (synchronises the stream). */
+int stepth_stats_enable(stepth_engine *engine, int enable);
+int stepth_get_stats(stepth_engine *engine, stepth_stats *out);
+
+/*
+ * Timing hook for bench.py's roofline leg: brackets the dominant kernel (ring_match or
+ * sad_match) of every subsequent call with HIP events on the engine's stream and
+ * accumulates; stepth_kernel_time_read() synchronises and returns the sum in milliseconds
+ * and the number of launches, then resets.
+ */
+int stepth_kernel_time_enable(stepth_engine *engine, int enable);
+int stepth_kernel_time_read(stepth_engine *engine, double *total_ms, uint64_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STEPTH_AMD_H */

@@ -1,0 +1,726 @@
+// engine.hip -- C-ABI of include/stepth_amd.h on top of the gfx950 kernels.
+//
+// Replaces the body of DepthImage::load_depth_from_additional,
+// /root/reference/src/depth_image.rs:96-132 (everything but the Gaussian resample tail).
+// No CPU fallback exists: without a HIP device every entry point fails with
+// STEPTH_ERR_NO_DEVICE / STEPTH_ERR_HIP.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/stepth_amd.h"
+#include "ring_kernels.h"
+#include "sad_kernels.h"
+
+using namespace stepth;
+
+static_assert(sizeof(stepth_group) == 20 && sizeof(GroupRec) == 20, "group layout");
+static_assert(sizeof(Query) == 16, "query layout");
+static_assert(sizeof(stepth_params) == 44 && sizeof(stepth_image) == 32 && sizeof(stepth_stats) == 24,
+              "C-ABI struct layout (mirrored by stepth_amd/_lib.py)");
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+} // namespace
+
+struct stepth_engine {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    DevBuf P, PT;          // packed additional image (rows / columns)
+    DevBuf stage_main, stage_add, stage_out, stage_groups;
+    DevBuf queries, raw, aux32, aux_pos, aux_found;
+    DevBuf sad_left, sad_right;
+    uint32_t *words = nullptr; // [0] max, [1] scratch max (host-visible copy target), [2..3] pad
+    unsigned long long *stats = nullptr; // [ring0_hits, probes]
+    uint64_t stats_groups = 0;
+    bool stats_enabled = false;
+
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    size_t events_used = 0;
+};
+
+namespace {
+
+int fail(stepth_engine *e, int status, const char *fmt, ...)
+{
+    if (e) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        e->err = buf;
+    }
+    return status;
+}
+
+#define HIP_TRY(e, call)                                                                      \
+    do {                                                                                      \
+        hipError_t _r = (call);                                                               \
+        if (_r != hipSuccess)                                                                 \
+            return fail((e), _r == hipErrorOutOfMemory ? STEPTH_ERR_OUT_OF_MEMORY             \
+                                                       : STEPTH_ERR_HIP,                      \
+                        "%s: %s (%s:%d)", #call, hipGetErrorString(_r), __FILE__, __LINE__);  \
+    } while (0)
+
+int reserve(stepth_engine *e, DevBuf &b, size_t bytes)
+{
+    if (bytes <= b.cap)
+        return STEPTH_OK;
+    if (b.p) {
+        HIP_TRY(e, hipStreamSynchronize(e->stream));
+        HIP_TRY(e, hipFree(b.p));
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    const size_t want = (bytes + 255) & ~(size_t)255;
+    HIP_TRY(e, hipMalloc(&b.p, want));
+    b.cap = want;
+    return STEPTH_OK;
+}
+
+void release(DevBuf &b)
+{
+    if (b.p)
+        (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+}
+
+#define TRY(expr)                                                                             \
+    do {                                                                                      \
+        int _s = (expr);                                                                      \
+        if (_s != STEPTH_OK)                                                                  \
+            return _s;                                                                        \
+    } while (0)
+
+// Brings a caller image onto the device if it is host memory.  Returns the device view.
+int to_device(stepth_engine *e, const stepth_image &im, DevBuf &stage, const uint8_t *&dptr,
+              size_t &dstride)
+{
+    const size_t row = (size_t)im.width * im.channels;
+    if (im.memory == STEPTH_MEM_DEVICE) {
+        dptr = static_cast<const uint8_t *>(im.data);
+        dstride = im.stride;
+        return STEPTH_OK;
+    }
+    const size_t pitch = (row + 15) & ~(size_t)15;
+    TRY(reserve(e, stage, pitch * im.height));
+    HIP_TRY(e, hipMemcpy2DAsync(stage.p, pitch, im.data, im.stride, row, im.height,
+                                hipMemcpyHostToDevice, e->stream));
+    dptr = static_cast<const uint8_t *>(stage.p);
+    dstride = pitch;
+    return STEPTH_OK;
+}
+
+int check_image(stepth_engine *e, const stepth_image *im, const char *name, uint32_t c0,
+                uint32_t c1)
+{
+    if (!im || !im->data)
+        return fail(e, STEPTH_ERR_BAD_ARG, "%s image is null", name);
+    if (im->width == 0 || im->height == 0 || im->width > 65535u || im->height > 65535u)
+        return fail(e, STEPTH_ERR_BAD_ARG, "%s image %ux%u: sides must be in 1..65535", name,
+                    im->width, im->height);
+    if (im->channels != c0 && im->channels != c1)
+        return fail(e, STEPTH_ERR_BAD_ARG, "%s image has %u channels", name, im->channels);
+    if (im->stride < (size_t)im->width * im->channels)
+        return fail(e, STEPTH_ERR_BAD_ARG, "%s image stride %zu < row bytes", name, im->stride);
+    if (im->memory != STEPTH_MEM_HOST && im->memory != STEPTH_MEM_DEVICE)
+        return fail(e, STEPTH_ERR_BAD_ARG, "%s image memory kind %u", name, im->memory);
+    return STEPTH_OK;
+}
+
+struct KernelTimer { // brackets the dominant kernel with events when timing is enabled
+    stepth_engine *e;
+    size_t slot = (size_t)-1;
+    explicit KernelTimer(stepth_engine *eng) : e(eng)
+    {
+        if (!e->timing)
+            return;
+        if (e->events_used == e->events.size()) {
+            hipEvent_t a = nullptr, b = nullptr;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess)
+                return;
+            e->events.emplace_back(a, b);
+        }
+        slot = e->events_used++;
+        (void)hipEventRecord(e->events[slot].first, e->stream);
+    }
+    ~KernelTimer()
+    {
+        if (slot != (size_t)-1)
+            (void)hipEventRecord(e->events[slot].second, e->stream);
+    }
+};
+
+inline uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
+
+// RGB8 additional image -> P / PT planes (src/depth_image.rs:96-100)
+int pack_additional(stepth_engine *e, const uint8_t *d_add, size_t stride, uint32_t wa,
+                    uint32_t ha, uint32_t &wp, uint32_t &hp)
+{
+    wp = round_up(wa, 64);
+    hp = round_up(ha, 64);
+    TRY(reserve(e, e->P, (size_t)ha * wp * 4));
+    TRY(reserve(e, e->PT, (size_t)wa * hp * 4));
+    PackArgs pa{d_add, stride, wa, ha, wp, hp, (uint32_t *)e->P.p, (uint32_t *)e->PT.p};
+    dim3 grid(wp / 32, hp / 32);
+    hipLaunchKernelGGL(pack_additional_kernel, grid, dim3(256), 0, e->stream, pa);
+    HIP_TRY(e, hipGetLastError());
+    return STEPTH_OK;
+}
+
+int launch_ring(stepth_engine *e, RingArgs &ra, int qmode)
+{
+    if (ra.n == 0)
+        return STEPTH_OK;
+    const uint32_t blocks = (ra.n + 255u) / 256u;
+    KernelTimer t(e);
+    if (e->stats_enabled) {
+        ra.stats = e->stats;
+        if (qmode == 0)
+            hipLaunchKernelGGL((ring_match_kernel<0, true>), dim3(blocks), dim3(256), 0, e->stream, ra);
+        else
+            hipLaunchKernelGGL((ring_match_kernel<1, true>), dim3(blocks), dim3(256), 0, e->stream, ra);
+    } else {
+        ra.stats = nullptr;
+        if (qmode == 0)
+            hipLaunchKernelGGL((ring_match_kernel<0, false>), dim3(blocks), dim3(256), 0, e->stream, ra);
+        else
+            hipLaunchKernelGGL((ring_match_kernel<1, false>), dim3(blocks), dim3(256), 0, e->stream, ra);
+    }
+    HIP_TRY(e, hipGetLastError());
+    return STEPTH_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+uint32_t stepth_abi_version(void) { return STEPTH_ABI_VERSION; }
+
+const char *stepth_status_string(int status)
+{
+    switch (status) {
+    case STEPTH_OK: return "ok";
+    case STEPTH_ERR_BAD_ARG: return "bad argument";
+    case STEPTH_ERR_SIZE_MISMATCH: return "Sizes don't match"; // src/depth_image.rs:45-48
+    case STEPTH_ERR_HIP: return "HIP runtime error";
+    case STEPTH_ERR_MAX_ZERO: return "every distance is zero (reference would divide by zero)";
+    case STEPTH_ERR_NO_DEVICE: return "no HIP device";
+    case STEPTH_ERR_OUT_OF_MEMORY: return "out of device memory";
+    default: return "unknown status";
+    }
+}
+
+int stepth_engine_create(int device_id, stepth_engine **out)
+{
+    if (!out)
+        return STEPTH_ERR_BAD_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return STEPTH_ERR_NO_DEVICE;
+    if (device_id < 0 && hipGetDevice(&device_id) != hipSuccess)
+        return STEPTH_ERR_NO_DEVICE;
+    if (device_id >= count)
+        return STEPTH_ERR_NO_DEVICE;
+    stepth_engine *e = new (std::nothrow) stepth_engine();
+    if (!e)
+        return STEPTH_ERR_OUT_OF_MEMORY;
+    e->device = device_id;
+    if (hipSetDevice(device_id) != hipSuccess ||
+        hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipMalloc((void **)&e->words, 64) != hipSuccess ||
+        hipMalloc((void **)&e->stats, 64) != hipSuccess) {
+        stepth_engine_destroy(e);
+        return STEPTH_ERR_HIP;
+    }
+    e->stream = e->own_stream;
+    (void)hipMemsetAsync(e->words, 0, 64, e->stream);
+    (void)hipMemsetAsync(e->stats, 0, 64, e->stream);
+    *out = e;
+    return STEPTH_OK;
+}
+
+void stepth_engine_destroy(stepth_engine *e)
+{
+    if (!e)
+        return;
+    (void)hipSetDevice(e->device);
+    if (e->stream)
+        (void)hipStreamSynchronize(e->stream);
+    for (DevBuf *b : {&e->P, &e->PT, &e->stage_main, &e->stage_add, &e->stage_out,
+                      &e->stage_groups, &e->queries, &e->raw, &e->aux32, &e->aux_pos,
+                      &e->aux_found, &e->sad_left, &e->sad_right})
+        release(*b);
+    if (e->words)
+        (void)hipFree(e->words);
+    if (e->stats)
+        (void)hipFree(e->stats);
+    for (auto &ev : e->events) {
+        (void)hipEventDestroy(ev.first);
+        (void)hipEventDestroy(ev.second);
+    }
+    if (e->own_stream)
+        (void)hipStreamDestroy(e->own_stream);
+    delete e;
+}
+
+int stepth_engine_set_stream(stepth_engine *e, void *hip_stream)
+{
+    if (!e)
+        return STEPTH_ERR_BAD_ARG;
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    e->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : e->own_stream;
+    return STEPTH_OK;
+}
+
+int stepth_engine_sync(stepth_engine *e)
+{
+    if (!e)
+        return STEPTH_ERR_BAD_ARG;
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    return STEPTH_OK;
+}
+
+const char *stepth_last_error(const stepth_engine *e) { return e ? e->err.c_str() : "null engine"; }
+
+int stepth_depth_from_additional(stepth_engine *e, const stepth_image *main_im,
+                                 const stepth_image *add_im, const stepth_params *pp,
+                                 const stepth_group *groups, size_t n_groups,
+                                 uint32_t groups_memory, const stepth_image *depth_im,
+                                 uint32_t *max_out)
+{
+    if (!e)
+        return STEPTH_ERR_BAD_ARG;
+    if (!pp || pp->struct_size != sizeof(stepth_params))
+        return fail(e, STEPTH_ERR_BAD_ARG, "params null or struct_size mismatch");
+    TRY(check_image(e, main_im, "main", 3, 4));
+    TRY(check_image(e, add_im, "additional", 3, 3));
+    TRY(check_image(e, depth_im, "depth", 1, 1));
+    const stepth_params p = *pp;
+    const uint32_t W = main_im->width, H = main_im->height;
+    // DepthImage::load_depth, src/depth_image.rs:37-49
+    if (depth_im->width != W || depth_im->height != H)
+        return fail(e, STEPTH_ERR_SIZE_MISMATCH, "Sizes don't match: depth %ux%u vs image %ux%u",
+                    depth_im->width, depth_im->height, W, H);
+    const bool async = p.flags & STEPTH_FLAG_ASYNC;
+    const bool raw_only = p.flags & STEPTH_FLAG_RAW_ONLY;
+    if (async && (main_im->memory != STEPTH_MEM_DEVICE || add_im->memory != STEPTH_MEM_DEVICE ||
+                  depth_im->memory != STEPTH_MEM_DEVICE ||
+                  (groups && groups_memory != STEPTH_MEM_DEVICE)))
+        return fail(e, STEPTH_ERR_BAD_ARG, "STEPTH_FLAG_ASYNC needs device memory everywhere");
+    uint32_t row0 = p.row_begin, row1 = p.row_end;
+    if (row0 == 0 && row1 == 0)
+        row1 = H;
+    if (row0 > row1 || row1 > H)
+        return fail(e, STEPTH_ERR_BAD_ARG, "row strip [%u,%u) outside 0..%u", row0, row1, H);
+    HIP_TRY(e, hipSetDevice(e->device));
+
+    const uint8_t *d_main = nullptr, *d_add = nullptr;
+    size_t ms = 0, as = 0;
+    TRY(to_device(e, *main_im, e->stage_main, d_main, ms));
+    TRY(to_device(e, *add_im, e->stage_add, d_add, as));
+
+    uint8_t *d_out = nullptr;
+    size_t os = 0;
+    if (depth_im->memory == STEPTH_MEM_DEVICE) {
+        d_out = static_cast<uint8_t *>(const_cast<void *>(depth_im->data));
+        os = depth_im->stride;
+    } else {
+        os = (W + 15u) & ~15u;
+        TRY(reserve(e, e->stage_out, os * H));
+        d_out = static_cast<uint8_t *>(e->stage_out.p);
+    }
+
+    hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(64), 0, e->stream, e->words, 2);
+
+    if (p.mode == STEPTH_MODE_SAD_WINDOW) {
+        if (groups)
+            return fail(e, STEPTH_ERR_BAD_ARG, "SAD mode takes no group list");
+        if (add_im->width != W || add_im->height != H)
+            return fail(e, STEPTH_ERR_SIZE_MISMATCH,
+                        "Sizes don't match: SAD mode needs equal image sizes");
+        if ((p.win & 1u) == 0 || p.win > 15 || p.d_max == 0 || p.d_max > 256)
+            return fail(e, STEPTH_ERR_BAD_ARG, "SAD mode: win must be odd <= 15, d_max in 1..256");
+        const uint32_t rows = row1 - row0;
+        TRY(reserve(e, e->raw, (size_t)W * std::max(rows, 1u)));
+        if (rows) {
+            SadArgs sa{};
+            sa.left = d_main;
+            sa.lstride = ms;
+            sa.lch = main_im->channels;
+            sa.right = d_add;
+            sa.rstride = as;
+            sa.w = W;
+            sa.h = H;
+            sa.row0 = row0;
+            sa.row1 = row1;
+            sa.d_max = p.d_max;
+            sa.win = p.win;
+            sa.thr = p.win * p.win * ((uint32_t)p.precision[0] + p.precision[1] + p.precision[2]);
+            sa.raw = static_cast<uint8_t *>(e->raw.p);
+            sa.max_word = e->words;
+            {
+                KernelTimer t(e);
+                int s = launch_sad(sa, e->stream);
+                if (s != STEPTH_OK)
+                    return fail(e, s, "sad_match launch failed: %s",
+                                hipGetErrorString(hipGetLastError()));
+            }
+            PaintArgs pa{};
+            pa.raw = sa.raw;
+            pa.max_word = e->words;
+            pa.identity = raw_only;
+            pa.out = d_out;
+            pa.ostride = os;
+            pa.w = W;
+            pa.h = H;
+            pa.row_begin = row0;
+            pa.row_end = row1;
+            pa.tile_w = pa.tile_h = 1;
+            pa.gx = W;
+            const size_t total = (size_t)rows * W;
+            const uint32_t blocks = (uint32_t)std::min<size_t>((total + 255) / 256, 2048);
+            hipLaunchKernelGGL(paint_tiles_kernel, dim3(blocks), dim3(256), 0, e->stream, pa);
+            HIP_TRY(e, hipGetLastError());
+        }
+    } else if (p.mode == STEPTH_MODE_RING_FIRST_HIT) {
+        uint32_t wp = 0, hp = 0;
+        TRY(pack_additional(e, d_add, as, add_im->width, add_im->height, wp, hp));
+
+        RingArgs ra{};
+        ra.P = (const uint32_t *)e->P.p;
+        ra.PT = (const uint32_t *)e->PT.p;
+        ra.wa = add_im->width;
+        ra.ha = add_im->height;
+        ra.wp = wp;
+        ra.hp = hp;
+        ra.max_steps = p.max_steps;
+        memcpy(ra.prec, p.precision, 3);
+        ra.max_word = e->words;
+
+        PaintArgs pa{};
+        pa.max_word = e->words;
+        pa.identity = raw_only;
+        pa.out = d_out;
+        pa.ostride = os;
+        pa.w = W;
+        pa.h = H;
+        pa.row_begin = row0;
+        pa.row_end = row1;
+
+        const uint32_t rows = row1 - row0;
+        int qmode;
+        const void *d_groups = nullptr;
+        if (groups) {
+            if (n_groups == 0 || n_groups > 0xFFFFFF00ull)
+                return fail(e, STEPTH_ERR_BAD_ARG, "group list of %zu entries", n_groups);
+            if (groups_memory == STEPTH_MEM_DEVICE) {
+                d_groups = groups;
+            } else {
+                TRY(reserve(e, e->stage_groups, n_groups * sizeof(stepth_group)));
+                HIP_TRY(e, hipMemcpyAsync(e->stage_groups.p, groups,
+                                          n_groups * sizeof(stepth_group), hipMemcpyHostToDevice,
+                                          e->stream));
+                d_groups = e->stage_groups.p;
+            }
+            ra.n = (uint32_t)n_groups;
+            TRY(reserve(e, e->queries, (size_t)ra.n * sizeof(Query)));
+            PrepArgs pr{};
+            pr.groups = d_groups;
+            pr.n = ra.n;
+            pr.row_begin = row0;
+            pr.row_end = row1;
+            memcpy(pr.prec, p.precision, 3);
+            pr.out = (Query *)e->queries.p;
+            hipLaunchKernelGGL(prep_list_kernel, dim3((ra.n + 255) / 256), dim3(256), 0, e->stream, pr);
+            HIP_TRY(e, hipGetLastError());
+            ra.queries = pr.out;
+            qmode = 1;
+            // groups not in the strip paint nothing; unpainted pixels keep the caller's bytes,
+            // so clear the strip first like ImageBuffer::from_pixel(.., Luma([0])) (:20)
+            if (rows)
+                HIP_TRY(e, hipMemset2DAsync(d_out + (size_t)row0 * os, os, 0, W, rows, e->stream));
+        } else {
+            if (p.tile_w == 0 || p.tile_h == 0)
+                return fail(e, STEPTH_ERR_BAD_ARG, "tile size 0");
+            if (row0 % p.tile_h != 0 || (row1 % p.tile_h != 0 && row1 != H))
+                return fail(e, STEPTH_ERR_BAD_ARG, "row strip [%u,%u) not aligned to tile_h %u",
+                            row0, row1, p.tile_h);
+            const uint32_t gx = (W + p.tile_w - 1) / p.tile_w;
+            const uint32_t gy = (rows + p.tile_h - 1) / p.tile_h;
+            ra.n = gx * gy;
+            pa.tile_w = p.tile_w;
+            pa.tile_h = p.tile_h;
+            pa.gx = gx;
+            if (p.tile_w == 1 && p.tile_h == 1) {
+                ra.main_px = d_main;
+                ra.mstride = ms;
+                ra.mch = main_im->channels;
+                ra.w = W;
+                ra.row0 = row0;
+                qmode = 0;
+            } else {
+                TRY(reserve(e, e->queries, (size_t)std::max(ra.n, 1u) * sizeof(Query)));
+                PrepArgs pr{};
+                pr.main_px = d_main;
+                pr.mstride = ms;
+                pr.mch = main_im->channels;
+                pr.w = W;
+                pr.h = H;
+                pr.tile_w = p.tile_w;
+                pr.tile_h = p.tile_h;
+                pr.gx = gx;
+                pr.gy = gy;
+                pr.n = ra.n;
+                pr.row_begin = row0;
+                pr.row_end = row1;
+                memcpy(pr.prec, p.precision, 3);
+                pr.out = (Query *)e->queries.p;
+                if (ra.n) {
+                    hipLaunchKernelGGL(prep_tiles_kernel, dim3((ra.n + 255) / 256), dim3(256), 0,
+                                       e->stream, pr);
+                    HIP_TRY(e, hipGetLastError());
+                }
+                ra.queries = pr.out;
+                qmode = 1;
+            }
+        }
+        TRY(reserve(e, e->raw, std::max<size_t>(ra.n, 4)));
+        ra.raw = static_cast<uint8_t *>(e->raw.p);
+        if (e->stats_enabled) {
+            HIP_TRY(e, hipMemsetAsync(e->stats, 0, 16, e->stream));
+            e->stats_groups = ra.n;
+        }
+        TRY(launch_ring(e, ra, qmode));
+
+        pa.raw = ra.raw;
+        pa.groups = d_groups;
+        pa.n = ra.n;
+        if (rows && ra.n) {
+            if (groups) {
+                hipLaunchKernelGGL(paint_list_kernel, dim3((ra.n + 3) / 4), dim3(256), 0, e->stream, pa);
+            } else if (qmode == 0 && (W & 3u) == 0 && (os & 3u) == 0 &&
+                       (reinterpret_cast<uintptr_t>(d_out) & 3u) == 0) {
+                const size_t total = (size_t)rows * (W / 4);
+                const uint32_t blocks = (uint32_t)std::min<size_t>((total + 255) / 256, 2048);
+                hipLaunchKernelGGL(paint_1x1_vec4_kernel, dim3(blocks), dim3(256), 0, e->stream, pa);
+            } else {
+                const size_t total = (size_t)rows * W;
+                const uint32_t blocks = (uint32_t)std::min<size_t>((total + 255) / 256, 2048);
+                hipLaunchKernelGGL(paint_tiles_kernel, dim3(blocks), dim3(256), 0, e->stream, pa);
+            }
+            HIP_TRY(e, hipGetLastError());
+        }
+    } else {
+        return fail(e, STEPTH_ERR_BAD_ARG, "unknown mode %u", p.mode);
+    }
+
+    if (async) {
+        if (max_out)
+            HIP_TRY(e, hipMemcpyAsync(max_out, e->words, 4, hipMemcpyDeviceToDevice, e->stream));
+        return STEPTH_OK;
+    }
+    uint32_t mx = 0;
+    HIP_TRY(e, hipMemcpyAsync(&mx, e->words, 4, hipMemcpyDeviceToHost, e->stream));
+    if (depth_im->memory == STEPTH_MEM_HOST && row1 > row0)
+        HIP_TRY(e, hipMemcpy2DAsync(
+                       static_cast<uint8_t *>(const_cast<void *>(depth_im->data)) +
+                           (size_t)row0 * depth_im->stride,
+                       depth_im->stride, d_out + (size_t)row0 * os, os, W, row1 - row0,
+                       hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    if (max_out)
+        *max_out = mx;
+    if (mx == 0 && !raw_only)
+        return fail(e, STEPTH_ERR_MAX_ZERO,
+                    "every group's distance is 0; output is all zero (reference: divide by zero, "
+                    "src/depth_image.rs:127)");
+    return STEPTH_OK;
+}
+
+int stepth_normalise_rows(stepth_engine *e, const stepth_image *rows, const uint32_t *max_ptr,
+                          uint32_t max_memory, uint32_t flags)
+{
+    if (!e)
+        return STEPTH_ERR_BAD_ARG;
+    TRY(check_image(e, rows, "rows", 1, 1));
+    if (!max_ptr)
+        return fail(e, STEPTH_ERR_BAD_ARG, "max_ptr is null");
+    const bool async = flags & STEPTH_FLAG_ASYNC;
+    if (async && (rows->memory != STEPTH_MEM_DEVICE || max_memory != STEPTH_MEM_DEVICE))
+        return fail(e, STEPTH_ERR_BAD_ARG, "STEPTH_FLAG_ASYNC needs device memory everywhere");
+    HIP_TRY(e, hipSetDevice(e->device));
+    uint32_t mx_host = 0;
+    const uint32_t *d_max = nullptr;
+    if (max_memory == STEPTH_MEM_DEVICE) {
+        d_max = max_ptr;
+        if (!async)
+            HIP_TRY(e, hipMemcpyAsync(&mx_host, max_ptr, 4, hipMemcpyDeviceToHost, e->stream));
+    } else {
+        mx_host = *max_ptr;
+        HIP_TRY(e, hipMemcpyAsync(e->words + 1, &mx_host, 4, hipMemcpyHostToDevice, e->stream));
+        d_max = e->words + 1;
+    }
+    NormArgs na{};
+    na.w = rows->width;
+    na.rows = rows->height;
+    na.max_word = d_max;
+    if (rows->memory == STEPTH_MEM_DEVICE) {
+        na.data = static_cast<uint8_t *>(const_cast<void *>(rows->data));
+        na.stride = rows->stride;
+    } else {
+        const uint8_t *dp = nullptr;
+        size_t ds = 0;
+        TRY(to_device(e, *rows, e->stage_out, dp, ds));
+        na.data = const_cast<uint8_t *>(dp);
+        na.stride = ds;
+    }
+    const size_t total = (size_t)na.rows * na.w;
+    const uint32_t blocks = (uint32_t)std::min<size_t>((total + 255) / 256, 2048);
+    hipLaunchKernelGGL(normalise_rows_kernel, dim3(blocks), dim3(256), 0, e->stream, na);
+    HIP_TRY(e, hipGetLastError());
+    if (async)
+        return STEPTH_OK;
+    if (rows->memory == STEPTH_MEM_HOST)
+        HIP_TRY(e, hipMemcpy2DAsync(const_cast<void *>(rows->data), rows->stride, na.data,
+                                    na.stride, na.w, na.rows, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    if (mx_host == 0)
+        return fail(e, STEPTH_ERR_MAX_ZERO, "max is 0; rows zeroed");
+    return STEPTH_OK;
+}
+
+int stepth_distance_dot_array_batch(stepth_engine *e, const stepth_image *array,
+                                    const uint8_t *what, const uint32_t *from_xy, size_t n,
+                                    uint32_t max, const uint8_t precision[3], uint8_t *found,
+                                    uint32_t *dist, uint32_t *pos_xy)
+{
+    if (!e)
+        return STEPTH_ERR_BAD_ARG;
+    TRY(check_image(e, array, "array", 3, 3));
+    if (!what || !from_xy || !precision || !found || !dist || !pos_xy)
+        return fail(e, STEPTH_ERR_BAD_ARG, "null pointer argument");
+    if (n == 0)
+        return STEPTH_OK;
+    if (n > 0x7FFFFFFFull)
+        return fail(e, STEPTH_ERR_BAD_ARG, "too many queries");
+    HIP_TRY(e, hipSetDevice(e->device));
+    const uint8_t *d_add = nullptr;
+    size_t as = 0;
+    TRY(to_device(e, *array, e->stage_add, d_add, as));
+    uint32_t wp = 0, hp = 0;
+    TRY(pack_additional(e, d_add, as, array->width, array->height, wp, hp));
+
+    std::vector<Query> qs(n);
+    for (size_t i = 0; i < n; ++i) {
+        qs[i].cx = from_xy[2 * i]; // helpers.rs:16: from.tuplexy()
+        qs[i].cy = from_xy[2 * i + 1];
+        make_box(what + 3 * i, precision, qs[i].lo, qs[i].hi);
+    }
+    TRY(reserve(e, e->queries, n * sizeof(Query)));
+    TRY(reserve(e, e->raw, std::max<size_t>(n, 4)));
+    TRY(reserve(e, e->aux32, n * 4));
+    TRY(reserve(e, e->aux_pos, n * 8));
+    TRY(reserve(e, e->aux_found, std::max<size_t>(n, 4)));
+    HIP_TRY(e, hipMemcpyAsync(e->queries.p, qs.data(), n * sizeof(Query), hipMemcpyHostToDevice,
+                              e->stream));
+    hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(64), 0, e->stream, e->words, 2);
+    RingArgs ra{};
+    ra.P = (const uint32_t *)e->P.p;
+    ra.PT = (const uint32_t *)e->PT.p;
+    ra.wa = array->width;
+    ra.ha = array->height;
+    ra.wp = wp;
+    ra.hp = hp;
+    ra.queries = (const Query *)e->queries.p;
+    ra.n = (uint32_t)n;
+    ra.max_steps = max;
+    memcpy(ra.prec, precision, 3);
+    ra.raw = (uint8_t *)e->raw.p;
+    ra.raw32 = (uint32_t *)e->aux32.p;
+    ra.pos = (uint32_t *)e->aux_pos.p;
+    ra.found = (uint8_t *)e->aux_found.p;
+    ra.max_word = e->words;
+    if (e->stats_enabled) {
+        HIP_TRY(e, hipMemsetAsync(e->stats, 0, 16, e->stream));
+        e->stats_groups = n;
+    }
+    TRY(launch_ring(e, ra, 1));
+    HIP_TRY(e, hipMemcpyAsync(dist, ra.raw32, n * 4, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipMemcpyAsync(pos_xy, ra.pos, n * 8, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipMemcpyAsync(found, ra.found, n, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    return STEPTH_OK;
+}
+
+int stepth_stats_enable(stepth_engine *e, int enable)
+{
+    if (!e)
+        return STEPTH_ERR_BAD_ARG;
+    e->stats_enabled = enable != 0;
+    e->stats_groups = 0;
+    HIP_TRY(e, hipMemsetAsync(e->stats, 0, 16, e->stream));
+    return STEPTH_OK;
+}
+
+int stepth_get_stats(stepth_engine *e, stepth_stats *out)
+{
+    if (!e || !out)
+        return STEPTH_ERR_BAD_ARG;
+    if (!e->stats_enabled)
+        return fail(e, STEPTH_ERR_BAD_ARG, "stats are not enabled (stepth_stats_enable)");
+    unsigned long long h[2] = {0, 0};
+    HIP_TRY(e, hipMemcpyAsync(h, e->stats, 16, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    out->groups = e->stats_groups;
+    out->ring0_hits = h[0];
+    out->probes = h[1];
+    return STEPTH_OK;
+}
+
+int stepth_kernel_time_enable(stepth_engine *e, int enable)
+{
+    if (!e)
+        return STEPTH_ERR_BAD_ARG;
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    e->timing = enable != 0;
+    e->events_used = 0;
+    return STEPTH_OK;
+}
+
+int stepth_kernel_time_read(stepth_engine *e, double *total_ms, uint64_t *launches)
+{
+    if (!e || !total_ms || !launches)
+        return STEPTH_ERR_BAD_ARG;
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    double sum = 0;
+    for (size_t i = 0; i < e->events_used; ++i) {
+        float ms = 0;
+        HIP_TRY(e, hipEventElapsedTime(&ms, e->events[i].first, e->events[i].second));
+        sum += ms;
+    }
+    *total_ms = sum;
+    *launches = e->events_used;
+    e->events_used = 0;
+    return STEPTH_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,224 @@
+"""Thin Python handle over the C-ABI engine (include/stepth_amd.h).
+
+Host arrays are numpy uint8, device arrays are torch CUDA(=HIP) uint8 tensors; torch is only
+plumbing for device memory and streams.  Every compute call goes through libstepth_amd.so --
+there is no Python/numpy implementation of the path in this package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib as L
+
+
+class StepthError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"stepth status {status}: {message}")
+        self.status = status
+
+
+class MaxZeroError(StepthError):
+    """Every distance is 0 -- the reference panics here (src/depth_image.rs:127)."""
+
+
+def _is_tensor(a) -> bool:
+    return hasattr(a, "data_ptr") and hasattr(a, "is_cuda")
+
+
+def _describe(a, channels: Sequence[int], name: str) -> Tuple[L.Image, object]:
+    """-> (stepth_image, keepalive).  Accepts [H,W,C] (or [H,W] for 1 channel)."""
+    if _is_tensor(a):
+        import torch
+        if a.dtype != torch.uint8:
+            raise TypeError(f"{name}: expected uint8 tensor, got {a.dtype}")
+        if not a.is_cuda:
+            raise TypeError(f"{name}: torch tensors must live on the GPU (use numpy for host)")
+        t = a if a.dim() == 3 else a.unsqueeze(-1)
+        if t.dim() != 3 or t.shape[2] not in channels:
+            raise ValueError(f"{name}: shape {tuple(a.shape)} not [H,W,{list(channels)}]")
+        if t.stride(2) != 1 or t.stride(1) != t.shape[2]:
+            raise ValueError(f"{name}: pixels must be contiguous within a row")
+        im = L.Image(t.data_ptr(), t.shape[1], t.shape[0], t.shape[2], L.MEM_DEVICE,
+                     t.stride(0) if t.shape[0] > 1 else t.shape[1] * t.shape[2])
+        return im, a
+    arr = np.asarray(a)
+    if arr.dtype != np.uint8:
+        raise TypeError(f"{name}: expected uint8 array, got {arr.dtype}")
+    v = arr if arr.ndim == 3 else arr[..., None]
+    if v.ndim != 3 or v.shape[2] not in channels:
+        raise ValueError(f"{name}: shape {arr.shape} not [H,W,{list(channels)}]")
+    if v.shape[0] and v.shape[1] and (v.strides[2] != 1 or v.strides[1] != v.shape[2]):
+        raise ValueError(f"{name}: pixels must be contiguous within a row")
+    stride = v.strides[0] if v.shape[0] > 1 else v.shape[1] * v.shape[2]
+    im = L.Image(v.ctypes.data, v.shape[1], v.shape[0], v.shape[2], L.MEM_HOST, stride)
+    return im, v
+
+
+def _u8x3(v) -> "C.Array":
+    v = [int(x) for x in v]
+    if len(v) != 3 or any(x < 0 or x > 255 for x in v):
+        raise ValueError("precision must be three u8 values")
+    return (C.c_uint8 * 3)(*v)
+
+
+GROUP_DTYPE = np.dtype([("x", "<u4"), ("y", "<u4"), ("w", "<u4"), ("h", "<u4"),
+                        ("value", "u1", (3,)), ("pad", "u1")])
+
+
+class Engine:
+    """One engine per device/stream (stepth_engine_create)."""
+
+    def __init__(self, device: int = -1):
+        self._lib = L.load()
+        h = C.c_void_p()
+        st = self._lib.stepth_engine_create(device, C.byref(h))
+        if st != L.OK:
+            raise StepthError(st, self._lib.stepth_status_string(st).decode())
+        self._h = h
+
+    # -- lifetime -------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.stepth_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, st: int):
+        if st == L.OK:
+            return
+        msg = self._lib.stepth_last_error(self._h).decode() or \
+            self._lib.stepth_status_string(st).decode()
+        raise (MaxZeroError if st == L.ERR_MAX_ZERO else StepthError)(st, msg)
+
+    def set_stream(self, hip_stream: Optional[int]):
+        self._check(self._lib.stepth_engine_set_stream(self._h, hip_stream))
+
+    def use_torch_stream(self):
+        import torch
+        self.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    def sync(self):
+        self._check(self._lib.stepth_engine_sync(self._h))
+
+    # -- the path -------------------------------------------------------------------------
+    def depth_from_additional(self, main, additional, precision, *, max_steps: int = 255,
+                              tile: Tuple[int, int] = (1, 1), groups=None,
+                              mode: int = L.MODE_RING_FIRST_HIT, d_max: int = 0, win: int = 0,
+                              rows: Optional[Tuple[int, int]] = None, raw_only: bool = False,
+                              out=None, max_out=None, asynchronous: bool = False):
+        """stepth_depth_from_additional.  Returns (depth [H,W] u8, max or None).
+
+        numpy in -> numpy out (synchronous).  torch CUDA tensors in -> tensor out; with
+        asynchronous=True nothing is synchronised and `max_out` must be a CUDA int32/uint32
+        tensor (or None)."""
+        mi, k1 = _describe(main, (3, 4), "main")
+        ai, k2 = _describe(additional, (3,), "additional")
+        dev = _is_tensor(main)
+        if dev != _is_tensor(additional):
+            raise TypeError("main and additional must both be numpy or both be CUDA tensors")
+        h, w = mi.height, mi.width
+        if out is None:
+            if dev:
+                import torch
+                out = torch.zeros((h, w), dtype=torch.uint8, device=main.device)
+            else:
+                out = np.zeros((h, w), np.uint8)
+        di, k3 = _describe(out, (1,), "depth")
+        p = L.Params()
+        p.struct_size = C.sizeof(L.Params)
+        p.mode = mode
+        p.precision = _u8x3(precision)
+        p.max_steps = max_steps
+        p.tile_w, p.tile_h = tile
+        p.d_max, p.win = d_max, win
+        if rows is not None:
+            p.row_begin, p.row_end = rows
+            if rows[0] == rows[1]:
+                return out, 0  # empty strip; 0,0 would mean "all rows" in the C-ABI
+        p.flags = (L.FLAG_ASYNC if asynchronous else 0) | (L.FLAG_RAW_ONLY if raw_only else 0)
+        gptr, gn, gmem, k4 = None, 0, L.MEM_HOST, None
+        if groups is not None:
+            if _is_tensor(groups):
+                gptr, gn, gmem, k4 = groups.data_ptr(), groups.numel() // 20, L.MEM_DEVICE, groups
+            else:
+                k4 = np.ascontiguousarray(groups, dtype=GROUP_DTYPE)
+                gptr, gn = k4.ctypes.data, len(k4)
+        if asynchronous:
+            mptr = max_out.data_ptr() if max_out is not None else None
+            st = self._lib.stepth_depth_from_additional(self._h, C.byref(mi), C.byref(ai),
+                                                        C.byref(p), gptr, gn, gmem,
+                                                        C.byref(di), mptr)
+            self._check(st)
+            return out, None
+        mx = C.c_uint32(0)
+        st = self._lib.stepth_depth_from_additional(self._h, C.byref(mi), C.byref(ai),
+                                                    C.byref(p), gptr, gn, gmem, C.byref(di),
+                                                    C.cast(C.byref(mx), C.c_void_p))
+        del k1, k2, k3, k4
+        self._check(st)
+        return out, int(mx.value)
+
+    def normalise_rows(self, rows, max_value, asynchronous: bool = False):
+        """stepth_normalise_rows, in place.  max_value: int (host) or CUDA tensor (device)."""
+        ri, _k = _describe(rows, (1,), "rows")
+        flags = L.FLAG_ASYNC if asynchronous else 0
+        if _is_tensor(max_value):
+            st = self._lib.stepth_normalise_rows(self._h, C.byref(ri), max_value.data_ptr(),
+                                                 L.MEM_DEVICE, flags)
+        else:
+            mx = C.c_uint32(int(max_value))
+            st = self._lib.stepth_normalise_rows(self._h, C.byref(ri),
+                                                 C.cast(C.byref(mx), C.c_void_p), L.MEM_HOST,
+                                                 flags)
+        self._check(st)
+        return rows
+
+    def distance_dot_array_batch(self, array, what, from_xy, max_steps: int, precision):
+        """helpers::distance_dot_array for n queries -> (found u8[n], dist u32[n], pos u32[n,2])."""
+        ai, _k = _describe(array, (3,), "array")
+        what = np.ascontiguousarray(what, dtype=np.uint8).reshape(-1, 3)
+        from_xy = np.ascontiguousarray(from_xy, dtype=np.uint32).reshape(-1, 2)
+        n = len(what)
+        if len(from_xy) != n:
+            raise ValueError("what and from_xy lengths differ")
+        found = np.zeros(n, np.uint8)
+        dist = np.zeros(n, np.uint32)
+        pos = np.zeros((n, 2), np.uint32)
+        st = self._lib.stepth_distance_dot_array_batch(
+            self._h, C.byref(ai), what.ctypes.data, from_xy.ctypes.data, n, max_steps,
+            C.cast(_u8x3(precision), C.c_void_p), found.ctypes.data, dist.ctypes.data,
+            pos.ctypes.data)
+        self._check(st)
+        return found, dist, pos
+
+    # -- instrumentation ------------------------------------------------------------------
+    def stats_enable(self, on: bool = True):
+        self._check(self._lib.stepth_stats_enable(self._h, int(on)))
+
+    def stats(self) -> dict:
+        s = L.Stats()
+        self._check(self._lib.stepth_get_stats(self._h, C.byref(s)))
+        return {"groups": int(s.groups), "ring0_hits": int(s.ring0_hits),
+                "probes": int(s.probes)}
+
+    def kernel_time_enable(self, on: bool = True):
+        self._check(self._lib.stepth_kernel_time_enable(self._h, int(on)))
+
+    def kernel_time_read(self) -> Tuple[float, int]:
+        ms, n = C.c_double(0), C.c_uint64(0)
+        self._check(self._lib.stepth_kernel_time_read(self._h, C.byref(ms), C.byref(n)))
+        return float(ms.value), int(n.value)

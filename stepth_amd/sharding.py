@@ -1,0 +1,121 @@
+"""Row-strip sharding of one frame across the GPUs of a node (one process per GPU).
+
+The reference is single-process (rayon threads, src/depth_image.rs:111-112); groups are
+independent in PASS 1 and coupled only through the global max (src/depth_image.rs:124).  So
+a frame shards by main-image row strips with exactly one real exchange:
+
+    PASS 1 on the rank's strip  ->  all_reduce(MAX) of one word per frame
+                                ->  PASS 2 on the strip (stepth_normalise_rows)
+                                ->  all_gather of the u8 depth rows
+
+`torch.distributed` is plumbing (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in
+the CPU tests).  The two compute steps are injected as callables so that the collective
+logic is testable without a GPU; `EngineStripWorker` is the product implementation on top of
+the HIP engine.  The additional image is replicated on every rank: a strip's search window
+lives in half-coordinate space ((y+1)/2 - 254 ... ) and is not a thin halo.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def strip_bounds(height: int, world: int, tile_h: int = 1) -> List[Tuple[int, int]]:
+    """Contiguous, tile-aligned, near-equal row strips; later ranks may get empty strips."""
+    if height <= 0 or world <= 0 or tile_h <= 0:
+        raise ValueError("height, world and tile_h must be positive")
+    tiles = (height + tile_h - 1) // tile_h
+    out, t0 = [], 0
+    for r in range(world):
+        t1 = t0 + tiles // world + (1 if r < tiles % world else 0)
+        out.append((min(t0 * tile_h, height), min(t1 * tile_h, height)))
+        t0 = t1
+    return out
+
+
+class StripWorker:
+    """What a rank must be able to do for one frame."""
+
+    def match_strip(self, frame, rows: Tuple[int, int]) -> Tuple[torch.Tensor, torch.Tensor]:
+        """PASS 1 on rows [r0,r1): -> (raw u8 [r1-r0, W], max int32 [1]), same device."""
+        raise NotImplementedError
+
+    def normalise(self, rows: torch.Tensor, max_word: torch.Tensor) -> None:
+        """PASS 2 in place: rows = rows*255/max (0 when max == 0)."""
+        raise NotImplementedError
+
+
+class EngineStripWorker(StripWorker):
+    """Strips on the HIP engine; frames are (main, additional) CUDA uint8 tensors."""
+
+    def __init__(self, engine, precision: Sequence[int], max_steps: int = 255,
+                 tile: Tuple[int, int] = (1, 1), mode: int = 0, d_max: int = 0, win: int = 0):
+        self.engine = engine
+        self.kw = dict(max_steps=max_steps, tile=tile, mode=mode, d_max=d_max, win=win)
+        self.precision = list(precision)
+
+    def match_strip(self, frame, rows):
+        main, add = frame
+        h, w = main.shape[0], main.shape[1]
+        full = torch.empty((h, w), dtype=torch.uint8, device=main.device)
+        mx = torch.zeros(1, dtype=torch.int32, device=main.device)
+        if rows[1] > rows[0]:
+            self.engine.depth_from_additional(main, add, self.precision, rows=rows,
+                                              raw_only=True, out=full, max_out=mx,
+                                              asynchronous=True, **self.kw)
+        return full[rows[0]:rows[1]], mx
+
+    def normalise(self, rows, max_word):
+        if rows.shape[0]:
+            self.engine.normalise_rows(rows, max_word, asynchronous=True)
+
+
+def sharded_depth(worker: StripWorker, frames: Sequence, height: int, width: int,
+                  tile_h: int = 1, group: Optional[dist.ProcessGroup] = None,
+                  device: Optional[torch.device] = None,
+                  sync: Optional[Callable[[], None]] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Depth maps of `frames`, every frame row-strip sharded over the ranks of `group`.
+
+    Returns (depth u8 [F, H, W], max int32 [F]) on every rank.  Collectives per call (not
+    per frame): one all_reduce(MAX) of F words and one all_gather of F*rows_per_rank*W bytes.
+    `sync` is called before each collective when the worker computes on a side stream."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    bounds = strip_bounds(height, world, tile_h)
+    r0, r1 = bounds[rank]
+    rows_max = max(b - a for a, b in bounds)
+    n = len(frames)
+
+    strips, maxes = [], []
+    for f in frames:
+        raw, mx = worker.match_strip(f, (r0, r1))
+        strips.append(raw)
+        maxes.append(mx)
+    if device is None:
+        device = maxes[0].device
+    max_all = torch.cat([m.reshape(1) for m in maxes]).to(torch.int32)
+    if world > 1:
+        if sync:
+            sync()
+        dist.all_reduce(max_all, op=dist.ReduceOp.MAX, group=group)  # src/depth_image.rs:124
+    for i, raw in enumerate(strips):
+        worker.normalise(raw, max_all[i:i + 1])  # src/depth_image.rs:125-129
+
+    if world == 1:
+        return torch.stack([s for s in strips]), max_all
+
+    send = torch.zeros((n, rows_max, width), dtype=torch.uint8, device=device)
+    if r1 > r0:
+        for i, raw in enumerate(strips):
+            send[i, : r1 - r0] = raw
+    recv = torch.empty((world, n, rows_max, width), dtype=torch.uint8, device=device)
+    if sync:
+        sync()
+    dist.all_gather_into_tensor(recv.view(-1), send.view(-1), group=group)
+    depth = torch.empty((n, height, width), dtype=torch.uint8, device=device)
+    for r, (a, b) in enumerate(bounds):
+        if b > a:
+            depth[:, a:b] = recv[r, :, : b - a]
+    return depth, max_all

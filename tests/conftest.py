@@ -1,0 +1,53 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _has_gpu() -> bool:
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    # -m gpu on a machine without a GPU: fail loudly instead of silently passing/skipping
+    if config.getoption("-m") == "gpu" and not _has_gpu():
+        for it in items:
+            if "gpu" in it.keywords:
+                it.add_marker(pytest.mark.xfail(reason="no GPU visible", run=False, strict=True))
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import oracle as O
+    O.build()
+    return O
+
+
+@pytest.fixture(scope="session")
+def asset():
+    """PIL-decoded reference assets, committed as PNG (tests/golden/make_asset_fixtures.py)."""
+    from PIL import Image
+    load = lambda n: np.asarray(Image.open(os.path.join(GOLDEN, f"asset_{n}.png")))
+    return {"main": load("main"), "additional": load("additional"), "depth": load("depth")}
+
+
+@pytest.fixture(scope="session")
+def engine():
+    from stepth_amd import Engine
+    e = Engine(0)
+    yield e
+    e.close()

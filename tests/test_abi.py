@@ -1,0 +1,123 @@
+"""CPU-side checks of the drop-in boundary: libstepth_amd.so loads, exports every symbol
+include/stepth_amd.h declares, struct layouts agree, and the product never reaches into
+oracle/.  No compute calls (no GPU here)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from stepth_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    return _lib.load()
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "stepth_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(stepth_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_all_exported_and_bound(lib):
+    from stepth_amd import _lib
+    names = declared_functions()
+    assert len(names) >= 14
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/stepth_amd.h but not exported"
+    assert sorted(_lib.SYMBOLS) == names, "ctypes binding and header disagree"
+
+
+def test_abi_version_and_status_strings(lib):
+    from stepth_amd import _lib
+    assert lib.stepth_abi_version() == _lib.ABI_VERSION == 1
+    # the reference's fixed error text, src/depth_image.rs:45-48
+    assert lib.stepth_status_string(_lib.ERR_SIZE_MISMATCH) == b"Sizes don't match"
+    assert lib.stepth_status_string(0) == b"ok"
+
+
+def test_struct_layouts():
+    from stepth_amd import _lib
+    from stepth_amd.engine import GROUP_DTYPE
+    from oracle import oracle as O
+    assert C.sizeof(_lib.Group) == 20 == GROUP_DTYPE.itemsize == O.GROUP_DTYPE.itemsize
+    assert C.sizeof(_lib.Image) == 32
+    assert C.sizeof(_lib.Params) == 44  # static_assert'ed in csrc/engine.hip
+    assert C.sizeof(_lib.Stats) == 24
+    assert _lib.Params.flags.offset == 40 and _lib.Params.max_steps.offset == 12
+
+
+def test_null_arguments_fail_cleanly_without_a_device(lib):
+    from stepth_amd import _lib
+    assert lib.stepth_engine_create(0, None) == _lib.ERR_BAD_ARG
+    assert lib.stepth_engine_sync(None) == _lib.ERR_BAD_ARG
+    assert lib.stepth_last_error(None) == b"null engine"
+    lib.stepth_engine_destroy(None)  # no-op
+
+
+def test_engine_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from stepth_amd import Engine, StepthError
+    with pytest.raises(StepthError) as ei:
+        Engine(0)
+    assert ei.value.status in (-5, -3)
+
+
+def test_product_never_touches_the_oracle():
+    pkg = os.path.join(ROOT, "stepth_amd")
+    for base, _d, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp", ".hpp")) or f == "Makefile":
+                text = open(os.path.join(base, f), errors="replace").read()
+                for line in text.splitlines():
+                    code = line.split("#")[0] if f.endswith(".py") else line
+                    assert not re.search(r"(import|from|include|link|dlopen|CDLL).*oracle", code), \
+                        f"{f}: {line.strip()}"
+
+
+def test_depth_image_host_logic(tmp_path):
+    from PIL import Image
+    from stepth_amd import DepthImage, InvalidInput
+    rgb = np.random.default_rng(0).integers(0, 255, (6, 9, 3), dtype=np.uint8)
+    p = tmp_path / "m.png"
+    Image.fromarray(rgb).save(p)
+    img = DepthImage.open(str(p))
+    assert img.image.shape == (6, 9, 4) and (img.image[..., 3] == 255).all()
+    assert (img.image[..., :3] == rgb).all()
+    assert img.depth.shape == (6, 9) and not img.depth.any()  # from_pixel(.., Luma([0]))
+    assert (img.width(), img.height()) == (9, 6) == img.dimensions()
+    img.load_depth(np.full((6, 9), 7, np.uint8))
+    assert (img.depth == 7).all()
+    with pytest.raises(InvalidInput, match="Sizes don't match"):
+        img.load_depth(np.zeros((9, 6), np.uint8))
+    with pytest.raises(InvalidInput, match="Failed to open image"):
+        DepthImage.open(str(tmp_path / "missing.jpg"))
+    with pytest.raises(InvalidInput, match="Failed to open image"):
+        img.open_depth_from_additional(str(tmp_path / "missing.jpg"), [36, 36, 36])
+    with pytest.raises(InvalidInput, match="Failed to open image"):
+        img.open_depth(str(tmp_path / "missing.jpg"))
+    d = DepthImage()
+    assert d.image.shape == (0, 0, 4) and d.depth.shape == (0, 0)
+    c = img.clone()
+    c.depth[:] = 1
+    assert (img.depth == 7).all()
+
+
+def test_strip_bounds():
+    from stepth_amd.sharding import strip_bounds
+    assert strip_bounds(1080, 8) == [(135 * i, 135 * (i + 1)) for i in range(8)]
+    b = strip_bounds(10, 4)
+    assert b == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    b = strip_bounds(1080, 8, tile_h=5)
+    assert b[0][0] == 0 and b[-1][1] == 1080
+    assert all(a % 5 == 0 for a, _ in b) and all(x[1] == y[0] for x, y in zip(b, b[1:]))
+    assert strip_bounds(3, 8)[3:] == [(3, 3)] * 5
+    assert strip_bounds(7, 2, tile_h=5) == [(0, 5), (5, 7)]

@@ -1,0 +1,357 @@
+"""GPU parity of the reference-exact mode: the HIP path, called through the C-ABI
+(libstepth_amd.so), against the CPU oracle on the same inputs.  Bit-exact everywhere (u8
+depth, u32 distances, hit positions); integer work has no tolerance."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+P36 = [36, 36, 36]
+
+
+def scan_cells(cx, cy, s):
+    out = []
+    for i in (cy + s, cy - s):
+        out += [(j, i) for j in range(cx - s, cx + s + 1)]
+    for i in (cx + s, cx - s):
+        out += [(i, j) for j in range(cy - s, cy + s + 1)]
+    return out
+
+
+def oracle_batch(oracle, array, what, from_xy, max_steps, prec):
+    if int(from_xy.max(initial=0)) >= 2 ** 31:  # 2*from would wrap: query one by one
+        out = {"found": np.zeros(len(what), np.uint8), "raw32": np.zeros(len(what), np.uint32),
+               "pos": np.zeros((len(what), 2), np.uint32)}
+        for i in range(len(what)):
+            res = oracle.distance_dot_array(what[i], array, tuple(int(v) for v in from_xy[i]),
+                                            max_steps, prec)
+            if res is not None:
+                out["found"][i], out["raw32"][i], out["pos"][i] = 1, res[0], res[1]
+        return out
+    g = np.zeros(len(what), oracle.GROUP_DTYPE)
+    # middle = ((x+w)/2, (y+h)/2): x = 2*fx, w = 0 reproduces an arbitrary `from`
+    g["x"], g["y"] = 2 * from_xy[:, 0].astype(np.uint64), 2 * from_xy[:, 1].astype(np.uint64)
+    g["value"] = what
+    return oracle.match_groups(g, array, max_steps, prec)
+
+
+def check_batch(engine, oracle, array, what, from_xy, max_steps, prec):
+    what = np.asarray(what, np.uint8).reshape(-1, 3)
+    from_xy = np.asarray(from_xy, np.uint32).reshape(-1, 2)
+    found, dist, pos = engine.distance_dot_array_batch(array, what, from_xy, max_steps, prec)
+    ref = oracle_batch(oracle, array, what, from_xy, max_steps, prec)
+    np.testing.assert_array_equal(found, ref["found"])
+    np.testing.assert_array_equal(dist, ref["raw32"])
+    np.testing.assert_array_equal(pos, ref["pos"])
+    return found, dist, pos
+
+
+# ---- helpers::distance_dot_array in isolation (src/helpers.rs:9-54) ----------------------
+
+@pytest.mark.parametrize("s", [1, 2, 7, 8, 9, 31, 32, 33, 40])
+def test_single_match_at_every_scan_position(engine, oracle, s):
+    """one matching cell, placed at every position of ring s (covers the offset-table rings
+    1..7, the table/side-loop seam at 8 and the 64-/128-cell chunk seams at 32/33)"""
+    n = 2 * s + 5
+    cx = cy = n // 2
+    cells = sorted(set(scan_cells(cx, cy, s)))
+    if len(cells) > 80:
+        cells = cells[:: len(cells) // 80 + 1] + cells[-3:]
+    hit = [200, 150, 100]
+    for (x, y) in cells:
+        a = np.zeros((n, n, 3), np.uint8)
+        a[y, x] = hit
+        f, d, p = check_batch(engine, oracle, a, [hit], [[cx, cy]], 255, [10, 10, 10])
+        assert f[0] == 1 and tuple(p[0]) == (x, y)
+
+
+@pytest.mark.parametrize("s", [1, 3, 8, 20, 70])
+def test_two_matches_first_in_scan_order_wins(engine, oracle, s):
+    rng = np.random.default_rng(s)
+    n = 2 * s + 3
+    cx = cy = n // 2
+    order = scan_cells(cx, cy, s)
+    arrays, exp = [], []
+    for _ in range(24):
+        ia, ib = sorted(rng.choice(len(order), 2, replace=False))
+        a = np.zeros((n, n, 3), np.uint8)
+        a[order[ia][1], order[ia][0]] = 255
+        a[order[ib][1], order[ib][0]] = 255
+        f, d, p = check_batch(engine, oracle, a, [[255] * 3], [[cx, cy]], 255, [5, 5, 5])
+        assert tuple(p[0]) == order[ia]
+
+
+def test_random_queries_on_noise_and_smooth_arrays(engine, oracle):
+    from stepth_amd import synth
+    rng = np.random.default_rng(11)
+    smooth, _, _ = synth.stereo_pair(301, 203, 32, seed=5)
+    noise = rng.integers(0, 256, (97, 131, 3), dtype=np.uint8)
+    for arr, prec in [(smooth, P36), (smooth, [8, 8, 8]), (noise, [40, 40, 40]),
+                      (noise, [20, 60, 30])]:
+        h, w = arr.shape[:2]
+        n = 1500
+        what = rng.integers(0, 256, (n, 3), dtype=np.uint8)
+        # half the queries take their colour from the array (so that hits exist)
+        ys, xs = rng.integers(0, h, n), rng.integers(0, w, n)
+        what[::2] = arr[ys[::2], xs[::2]]
+        from_xy = np.stack([rng.integers(0, w + 20, n), rng.integers(0, h + 20, n)], 1)
+        for ms in (255, 40, 3, 1, 0):
+            check_batch(engine, oracle, arr, what, from_xy, ms, prec)
+
+
+def test_centre_outside_and_degenerate_arrays(engine, oracle):
+    a = np.full((4, 6, 3), 77, np.uint8)
+    q = [[6, 0], [0, 4], [5, 3], [100000, 2], [2, 4000000000], [0, 0]]
+    f, d, p = check_batch(engine, oracle, a, [[77] * 3] * len(q), q, 255, [1, 1, 1])
+    assert f.tolist() == [0, 0, 1, 0, 0, 1]
+    one = np.array([[[9, 9, 9]]], np.uint8)
+    check_batch(engine, oracle, one, [[9, 9, 9], [9, 9, 10]], [[0, 0], [0, 0]], 255, [1, 1, 1])
+    row = np.zeros((1, 700, 3), np.uint8)
+    row[0, 650] = 50
+    f, d, p = check_batch(engine, oracle, row, [[50] * 3] * 2, [[10, 0], [400, 0]], 255, [1] * 3)
+    assert f.tolist() == [0, 1] and d[1] == 250
+    col = np.zeros((700, 1, 3), np.uint8)
+    col[3, 0] = 50
+    check_batch(engine, oracle, col, [[50] * 3] * 2, [[0, 200], [0, 300]], 255, [1] * 3)
+
+
+def test_precision_edges(engine, oracle):
+    rng = np.random.default_rng(3)
+    arr = rng.integers(0, 256, (40, 40, 3), dtype=np.uint8)
+    what = rng.integers(0, 256, (400, 3), dtype=np.uint8)
+    what[:50] = [0, 0, 0]
+    what[50:100] = [255, 255, 255]
+    fxy = rng.integers(0, 40, (400, 2))
+    for prec in ([0, 0, 0], [1, 1, 1], [255, 255, 255], [0, 255, 255], [255, 1, 128],
+                 [2, 200, 17]):
+        check_batch(engine, oracle, arr, what, fxy, 255, prec)
+
+
+def test_far_hits_and_distance_extremes(engine, oracle):
+    """hits at ring 254 (corner: distance 359 -> wraps to 103 as u8) and just beyond max"""
+    a = np.zeros((600, 600, 3), np.uint8)
+    a[300 + 254, 300 + 254] = 255
+    a[300 - 254, 300] = 254
+    f, d, p = check_batch(engine, oracle, a, [[255] * 3, [254] * 3, [253] * 3],
+                          [[300, 300]] * 3, 255, [1, 1, 1])
+    assert f.tolist() == [1, 1, 0] and d.tolist() == [359, 254, 0]
+    check_batch(engine, oracle, a, [[255] * 3], [[300, 300]], 254, [1, 1, 1])  # ring 254 cut off
+
+
+# ---- the whole path (src/depth_image.rs:96-132, no Gaussian tail) ------------------------
+
+def run_both(engine, oracle, main, add, prec, **kw):
+    ref = oracle.depth_from_additional(main, add, prec, kw.get("max_steps", 255),
+                                       kw.get("tile", (1, 1)), kw.get("groups"))
+    from stepth_amd import MaxZeroError
+    try:
+        depth, mx = engine.depth_from_additional(main, add, prec, **kw)
+        status = 0
+    except MaxZeroError:
+        status, depth, mx = -4, None, 0
+    assert status == ref["status"]
+    if status == 0:
+        assert mx == ref["max"]
+        np.testing.assert_array_equal(depth, ref["depth"])
+        raw, mx2 = engine.depth_from_additional(main, add, prec, raw_only=True, **kw)
+        np.testing.assert_array_equal(raw, ref["raw"])
+        assert mx2 == ref["max"]
+    return ref
+
+
+def test_asset_pair_bit_exact(engine, oracle, asset):
+    """config 1 of BASELINE.json: the reference's own 600x400 pair, precision [36;3]"""
+    ref = run_both(engine, oracle, asset["main"], asset["additional"], P36)
+    assert ref["max"] == 205
+
+
+@pytest.mark.parametrize("w,h,ms", [(64, 64, 255), (257, 131, 255), (640, 360, 128),
+                                     (333, 500, 64), (1, 1, 255), (3, 2, 255), (1, 300, 255),
+                                     (300, 1, 255)])
+def test_synthetic_pairs_1x1(engine, oracle, w, h, ms):
+    from stepth_amd import synth
+    l, r, _ = synth.stereo_pair(w, h, 32, seed=w * 7 + h)
+    for prec in (P36, [12, 12, 12]):
+        run_both(engine, oracle, l, r, prec, max_steps=ms)
+
+
+def test_rgba_main_and_strided_inputs(engine, oracle):
+    from stepth_amd import synth
+    l, r, _ = synth.stereo_pair(200, 120, 32, seed=9)
+    ref = oracle.depth_from_additional(l, r, P36, 255)
+    rgba = np.concatenate([l, np.full((120, 200, 1), 9, np.uint8)], axis=2)  # alpha ignored
+    d, mx = engine.depth_from_additional(rgba, r, P36)
+    np.testing.assert_array_equal(d, ref["depth"])
+    big = np.zeros((120, 260, 3), np.uint8)
+    big[:, :200] = r
+    lbig = np.zeros((120, 231, 3), np.uint8)
+    lbig[:, :200] = l
+    out = np.full((120, 300), 0xEE, np.uint8)
+    engine.depth_from_additional(lbig[:, :200], big[:, :200], P36, out=out[:, :200])
+    np.testing.assert_array_equal(out[:, :200], ref["depth"])
+    assert (out[:, 200:] == 0xEE).all()
+
+
+def test_different_sized_additional(engine, oracle):
+    from stepth_amd import synth
+    l, _, _ = synth.stereo_pair(160, 100, 16, seed=2)
+    _, r, _ = synth.stereo_pair(70, 45, 16, seed=2)   # smaller than main/2 in places
+    run_both(engine, oracle, l, r, P36)
+    _, r2, _ = synth.stereo_pair(400, 300, 16, seed=3)
+    run_both(engine, oracle, l, r2, P36)
+
+
+@pytest.mark.parametrize("tile", [(5, 5), (2, 3), (16, 16), (7, 1), (64, 64)])
+def test_uniform_tiles(engine, oracle, tile):
+    from stepth_amd import synth
+    l, r, _ = synth.stereo_pair(203, 117, 32, seed=tile[0])
+    run_both(engine, oracle, l, r, P36, tile=tile)
+
+
+def test_explicit_group_list(engine, oracle):
+    """a caller-supplied partition (the stand-in for disage::open::rgb_discrete's output)"""
+    from stepth_amd import synth
+    l, r, _ = synth.stereo_pair(128, 96, 32, seed=4)
+    rng = np.random.default_rng(0)
+    groups = []
+    def split(x, y, w, h, depth):
+        if depth == 0 or w < 2 or h < 2 or rng.random() < 0.15:
+            v = l[y:y + h, x:x + w].reshape(-1, 3).astype(np.uint64).sum(0) // (w * h)
+            groups.append((x, y, w, h, v))
+            return
+        if w >= h:
+            c = int(rng.integers(1, w))
+            split(x, y, c, h, depth - 1), split(x + c, y, w - c, h, depth - 1)
+        else:
+            c = int(rng.integers(1, h))
+            split(x, y, w, c, depth - 1), split(x, y + c, w, h - c, depth - 1)
+    split(0, 0, 128, 96, 9)
+    g = np.zeros(len(groups), oracle.GROUP_DTYPE)
+    for i, (x, y, w, h, v) in enumerate(groups):
+        g[i]["x"], g[i]["y"], g[i]["w"], g[i]["h"], g[i]["value"] = x, y, w, h, v
+    g = g[rng.permutation(len(g))]  # order in the Vec must not matter for results
+    run_both(engine, oracle, l, r, P36, groups=g)
+
+
+def test_max_zero_is_a_defined_outcome(engine, oracle):
+    from stepth_amd import MaxZeroError
+    flat = np.full((20, 30, 3), 100, np.uint8)
+    ref = oracle.depth_from_additional(flat, flat, P36)
+    assert ref["status"] == oracle.ERR_MAX_ZERO
+    out = np.full((20, 30), 5, np.uint8)
+    with pytest.raises(MaxZeroError):
+        engine.depth_from_additional(flat, flat, P36, out=out)
+    assert not out.any()
+    # nothing matches anywhere -> all None -> all 0 -> same outcome
+    a, b = np.zeros((8, 8, 3), np.uint8), np.full((8, 8, 3), 255, np.uint8)
+    with pytest.raises(MaxZeroError):
+        engine.depth_from_additional(a, b, [1, 1, 1])
+
+
+def test_size_mismatch_and_bad_arguments(engine):
+    from stepth_amd import StepthError
+    a = np.zeros((8, 8, 3), np.uint8)
+    with pytest.raises(StepthError) as ei:
+        engine.depth_from_additional(a, a, P36, out=np.zeros((8, 9), np.uint8))
+    assert ei.value.status == -2 and "Sizes don't match" in str(ei.value)
+    with pytest.raises(StepthError) as ei:
+        engine.depth_from_additional(a, a, P36, tile=(0, 1))
+    assert ei.value.status == -1
+    with pytest.raises(StepthError) as ei:
+        engine.depth_from_additional(a, a, P36, rows=(2, 20))
+    assert ei.value.status == -1
+
+
+def test_row_strips_compose_to_the_full_frame(engine, oracle):
+    """multi-GPU building block: PASS 1 per strip (RAW_ONLY), max over strips, PASS 2 per strip"""
+    from stepth_amd import synth
+    from stepth_amd.sharding import strip_bounds
+    l, r, _ = synth.stereo_pair(190, 143, 32, seed=12)
+    for tile in ((1, 1), (5, 5)):
+        ref = oracle.depth_from_additional(l, r, P36, 255, tile)
+        for world in (2, 3, 8):
+            out = np.zeros((143, 190), np.uint8)
+            maxes = []
+            for (r0, r1) in strip_bounds(143, world, tile[1]):
+                _, mx = engine.depth_from_additional(l, r, P36, tile=tile, rows=(r0, r1),
+                                                     raw_only=True, out=out)
+                maxes.append(mx)
+            np.testing.assert_array_equal(out, ref["raw"])
+            assert max(maxes) == ref["max"]
+            for (r0, r1) in strip_bounds(143, world, tile[1]):
+                if r1 > r0:
+                    engine.normalise_rows(out[r0:r1], max(maxes))
+            np.testing.assert_array_equal(out, ref["depth"])
+
+
+def test_device_memory_async_path(engine, oracle):
+    import torch
+    from stepth_amd import synth
+    l, r, _ = synth.stereo_pair(320, 200, 32, seed=21)
+    ref = oracle.depth_from_additional(l, r, P36, 128)
+    dl, dr = torch.from_numpy(l).cuda(), torch.from_numpy(r).cuda()
+    engine.use_torch_stream()
+    try:
+        mx = torch.zeros(1, dtype=torch.int32, device="cuda")
+        out, _ = engine.depth_from_additional(dl, dr, P36, max_steps=128, max_out=mx,
+                                              asynchronous=True)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(out.cpu().numpy(), ref["depth"])
+        assert int(mx.item()) == ref["max"]
+        out2, mx2 = engine.depth_from_additional(dl, dr, P36, max_steps=128)
+        np.testing.assert_array_equal(out2.cpu().numpy(), ref["depth"])
+        assert mx2 == ref["max"]
+    finally:
+        engine.set_stream(None)
+
+
+def test_stats_counters(engine, oracle, asset):
+    engine.stats_enable(True)
+    try:
+        engine.depth_from_additional(asset["main"], asset["additional"], P36)
+        s = engine.stats()
+    finally:
+        engine.stats_enable(False)
+    assert s["groups"] == 240000 and s["ring0_hits"] == 175117  # SURVEY.md 8c histogram
+    assert s["probes"] > 240000
+
+
+def test_depth_image_mirror_end_to_end(engine, oracle, asset, tmp_path):
+    """the README flow (Readme.md:11-16) through the host mirror"""
+    from PIL import Image
+    from stepth_amd import DepthImage
+    pm, pa = tmp_path / "main.png", tmp_path / "additional.png"
+    Image.fromarray(asset["main"]).save(pm)
+    Image.fromarray(asset["additional"]).save(pa)
+    img = DepthImage.open(str(pm))
+    img.open_depth_from_additional(str(pa), [255 // 7] * 3, engine=engine)
+    ref = oracle.depth_from_additional(asset["main"], asset["additional"], P36)
+    np.testing.assert_array_equal(img.depth, ref["depth"])
+    d = img.depth.astype(float)
+    assert np.corrcoef(d.ravel(), asset["depth"].astype(float).ravel())[0, 1] >= 0.975
+
+
+def test_full_size_properties_1080p(engine):
+    """BASELINE full size (1920x1080, d_max=128 -> max_steps) without the oracle: size-
+    independent properties -- strips compose, idempotence, max/normalise consistency,
+    ring-0 pixels are zero, every raw distance is reachable within max_steps."""
+    import torch
+    from stepth_amd import synth
+    l, r, _ = synth.stereo_pair(1920, 1080, 128, seed=0x5EED)
+    raw, mx = engine.depth_from_additional(l, r, P36, max_steps=128, raw_only=True)
+    depth, mx2 = engine.depth_from_additional(l, r, P36, max_steps=128)
+    depth_b, _ = engine.depth_from_additional(l, r, P36, max_steps=128)
+    np.testing.assert_array_equal(depth, depth_b)  # deterministic
+    assert mx == mx2 == int(raw.max()) and 0 < mx <= int(np.floor(np.hypot(127, 127)))
+    np.testing.assert_array_equal(depth, (raw.astype(np.uint32) * 255 // mx).astype(np.uint8))
+    # pixels whose own colour sits at their search centre must be 0
+    ys, xs = np.mgrid[0:1080, 0:1920]
+    centre = r[(ys + 1) // 2, (xs + 1) // 2].astype(int)
+    ring0 = (np.abs(centre - l.astype(int)) < 36).all(axis=2)
+    assert not raw[ring0].any()
+    assert (raw[~ring0] > 0).mean() > 0.9  # a miss at ring 0 gives d >= 1, or None -> 0
+    # two strips == full frame
+    out = np.zeros_like(raw)
+    for rows in ((0, 540), (540, 1080)):
+        engine.depth_from_additional(l, r, P36, max_steps=128, rows=rows, raw_only=True, out=out)
+    np.testing.assert_array_equal(out, raw)

@@ -1,0 +1,50 @@
+"""GPU parity of the windowed-SAD mode against the engine's own CPU statement
+(oracle_sad_rows).  This mode does not exist in the reference: parity here
+is self-consistency, bit-exact on the u8 disparity map."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def run_sad(engine, l, r, d_max, win, prec, **kw):
+    from stepth_amd import MODE_SAD_WINDOW
+    return engine.depth_from_additional(l, r, prec, mode=MODE_SAD_WINDOW, d_max=d_max, win=win,
+                                        **kw)
+
+
+@pytest.mark.parametrize("w,h,d_max,win", [(160, 48, 24, 5), (200, 90, 64, 5), (131, 77, 128, 5),
+                                            (96, 40, 32, 9), (64, 17, 256, 3), (70, 33, 16, 1),
+                                            (5, 4, 8, 5)])
+def test_sad_raw_matches_cpu_statement(engine, oracle, w, h, d_max, win):
+    from stepth_amd import synth
+    l, r, _ = synth.stereo_pair(w, h, min(d_max, 64), seed=w + d_max)
+    for prec in ([0, 0, 0], [4, 4, 4], [36, 36, 36]):
+        ref = oracle.sad_rows(l, r, d_max, win, prec)
+        raw, mx = run_sad(engine, l, r, d_max, win, prec, raw_only=True)
+        np.testing.assert_array_equal(raw, ref)
+        assert mx == int(ref.max())
+        if mx:
+            depth, _ = run_sad(engine, l, r, d_max, win, prec)
+            np.testing.assert_array_equal(depth, (ref.astype(np.uint32) * 255 // mx).astype(np.uint8))
+
+
+def test_sad_rgba_left_and_strips(engine, oracle):
+    from stepth_amd import synth
+    l, r, _ = synth.stereo_pair(150, 61, 32, seed=5)
+    ref = oracle.sad_rows(l, r, 32, 5, [3, 3, 3])
+    rgba = np.concatenate([l, np.zeros((61, 150, 1), np.uint8)], axis=2)
+    raw, _ = run_sad(engine, rgba, r, 32, 5, [3, 3, 3], raw_only=True)
+    np.testing.assert_array_equal(raw, ref)
+    out = np.zeros_like(ref)
+    for rows in ((0, 20), (20, 21), (21, 61)):
+        run_sad(engine, l, r, 32, 5, [3, 3, 3], raw_only=True, rows=rows, out=out)
+    np.testing.assert_array_equal(out, ref)
+
+
+def test_sad_recovers_planted_disparity(engine):
+    from stepth_amd import synth
+    l, r, disp = synth.stereo_pair(640, 360, 64, seed=2)
+    raw, _ = run_sad(engine, l, r, 64, 5, [0, 0, 0], raw_only=True)
+    inner = (slice(8, -8), slice(72, -8))
+    assert (np.abs(raw[inner].astype(int) - disp[inner]) <= 1).mean() > 0.7

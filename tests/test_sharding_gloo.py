@@ -1,0 +1,102 @@
+"""N>1 path on CPU: world_size-2 and -3 `gloo` process groups run the row-strip flow of
+stepth_amd/sharding.py (all_reduce(MAX) + all_gather) with the oracle standing in for the
+per-strip compute, and every rank must end up with the single-process result."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+class OracleStripWorker:
+    """test double for EngineStripWorker: same contract, CPU oracle inside"""
+
+    def __init__(self, prec, max_steps, tile):
+        from oracle import oracle as O
+        self.O, self.prec, self.max_steps, self.tile = O, prec, max_steps, tile
+
+    def match_strip(self, frame, rows):
+        main, add = frame
+        O = self.O
+        h, w = main.shape[:2]
+        g = O.uniform_groups(main, *self.tile)
+        sel = g[(g["y"] >= rows[0]) & (g["y"] < rows[1])]
+        out = np.zeros((h, w), np.uint8)
+        mx = 0
+        if len(sel):
+            m = O.match_groups(sel, add, self.max_steps, self.prec, threads=O.SERIAL)
+            out = O.paint(sel, m["raw"], w, h)
+            mx = int(m["raw"].max())
+        return torch.from_numpy(out[rows[0]:rows[1]].copy()), torch.tensor([mx], dtype=torch.int32)
+
+    def normalise(self, rows, max_word):
+        mx = int(max_word.item())
+        if rows.numel():
+            v = rows.to(torch.int32) * 255 // max(mx, 1) if mx else rows.to(torch.int32) * 0
+            rows.copy_(v.to(torch.uint8))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, tile, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from stepth_amd import synth
+        from stepth_amd.sharding import sharded_depth
+        frames = []
+        for seed in (1, 2):
+            l, r, _ = synth.stereo_pair(97, 61, 16, seed=seed)
+            frames.append((l, r))
+        wk = OracleStripWorker([36] * 3, 64, tile)
+        depth, mx = sharded_depth(wk, frames, 61, 97, tile_h=tile[1])
+        q.put((rank, depth.numpy(), mx.numpy()))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,tile", [(2, (1, 1)), (3, (1, 1)), (2, (5, 5))])
+def test_sharded_equals_single_process(world, tile):
+    from oracle import oracle as O
+    from stepth_amd import synth
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, tile, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for seed_i, seed in enumerate((1, 2)):
+        l, r, _ = synth.stereo_pair(97, 61, 16, seed=seed)
+        ref = O.depth_from_additional(l, r, [36] * 3, 64, tile)
+        for rank, depth, mx in results:
+            np.testing.assert_array_equal(depth[seed_i], ref["depth"])
+            assert int(mx[seed_i]) == ref["max"]
+
+
+def test_single_process_path_without_init():
+    from oracle import oracle as O
+    from stepth_amd import synth
+    from stepth_amd.sharding import sharded_depth
+    l, r, _ = synth.stereo_pair(50, 40, 16, seed=4)
+    wk = OracleStripWorker([36] * 3, 64, (1, 1))
+    depth, mx = sharded_depth(wk, [(l, r)], 40, 50)
+    ref = O.depth_from_additional(l, r, [36] * 3, 64)
+    np.testing.assert_array_equal(depth[0].numpy(), ref["depth"])
