@@ -66,6 +66,7 @@ def cpu_baseline(frame, args):
         O._lib = O.lib(lib_path)
     except Exception:
         O.lib()
+    O.set_threads(O.usable_cpus())
     l, r = frame
     prec = [args.precision] * 3
     if args.mode == "ring":

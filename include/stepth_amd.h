@@ -113,8 +113,11 @@ const char *stepth_status_string(int status);
 /* One engine per device/stream.  device_id < 0 = current device. */
 int stepth_engine_create(int device_id, stepth_engine **out);
 void stepth_engine_destroy(stepth_engine *engine);
-/* Use the caller's HIP stream (hipStream_t) instead of the engine's own; NULL restores it. */
+/* Run on the caller's HIP stream (a hipStream_t; NULL is HIP's default stream, which is what
+ * torch.cuda.current_stream() usually is) instead of the engine's own non-blocking stream;
+ * stepth_engine_reset_stream() goes back to the engine's own.  Both drain the old stream. */
 int stepth_engine_set_stream(stepth_engine *engine, void *hip_stream);
+int stepth_engine_reset_stream(stepth_engine *engine);
 int stepth_engine_sync(stepth_engine *engine);
 const char *stepth_last_error(const stepth_engine *engine);
 

@@ -84,6 +84,8 @@ def lib(path: Optional[str] = None):
                                   C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, u8p,
                                   C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
     L.oracle_hardware_threads.restype = C.c_int
+    L.oracle_set_threads.restype = None
+    L.oracle_set_threads.argtypes = [C.c_int]
     if path is None:
         _lib = L
     return L
@@ -208,3 +210,19 @@ def sad_rows(left: np.ndarray, right: np.ndarray, d_max: int, win: int, precisio
 
 def hardware_threads() -> int:
     return int(lib().oracle_hardware_threads())
+
+
+def usable_cpus() -> int:
+    """CPUs this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period) + 0.5)))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+def set_threads(n: int) -> None:
+    lib().oracle_set_threads(int(n))

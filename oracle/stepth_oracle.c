@@ -200,8 +200,14 @@ static void *match_dynamic_thread(void *arg)
     return NULL;
 }
 
+static int g_threads = 0; /* 0 = every online core */
+
+void oracle_set_threads(int n) { g_threads = n > 0 ? n : 0; }
+
 int oracle_hardware_threads(void)
 {
+    if (g_threads > 0)
+        return g_threads;
     long n = sysconf(_SC_NPROCESSORS_ONLN);
     return n > 0 ? (int)n : 1;
 }

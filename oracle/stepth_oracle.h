@@ -106,6 +106,9 @@ int oracle_sad_rows(const uint8_t *left, const uint8_t *right, uint32_t w, uint3
                     uint32_t win, const uint8_t precision[3], uint32_t row0, uint32_t row1,
                     int threads, uint8_t *raw);
 
+/* threads used by ORACLE_THREADS_ALLCORES: every online core, or the count set here (a
+ * container's CPU share is usually smaller than the host's core count) */
+void oracle_set_threads(int n);
 int oracle_hardware_threads(void);
 
 #ifdef __cplusplus

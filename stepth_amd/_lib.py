@@ -63,6 +63,7 @@ SYMBOLS = {
     "stepth_engine_create": (C.c_int, [C.c_int, _P(C.c_void_p)]),
     "stepth_engine_destroy": (None, [C.c_void_p]),
     "stepth_engine_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "stepth_engine_reset_stream": (C.c_int, [C.c_void_p]),
     "stepth_engine_sync": (C.c_int, [C.c_void_p]),
     "stepth_last_error": (C.c_char_p, [C.c_void_p]),
     "stepth_depth_from_additional": (C.c_int, [C.c_void_p, _P(Image), _P(Image), _P(Params),

@@ -263,8 +263,7 @@ void stepth_engine_destroy(stepth_engine *e)
     if (!e)
         return;
     (void)hipSetDevice(e->device);
-    if (e->stream)
-        (void)hipStreamSynchronize(e->stream);
+    (void)hipStreamSynchronize(e->stream);
     for (DevBuf *b : {&e->P, &e->PT, &e->stage_main, &e->stage_add, &e->stage_out,
                       &e->stage_groups, &e->queries, &e->raw, &e->aux32, &e->aux_pos,
                       &e->aux_found, &e->sad_left, &e->sad_right})
@@ -287,7 +286,16 @@ int stepth_engine_set_stream(stepth_engine *e, void *hip_stream)
     if (!e)
         return STEPTH_ERR_BAD_ARG;
     HIP_TRY(e, hipStreamSynchronize(e->stream));
-    e->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : e->own_stream;
+    e->stream = static_cast<hipStream_t>(hip_stream); // nullptr = HIP's default stream
+    return STEPTH_OK;
+}
+
+int stepth_engine_reset_stream(stepth_engine *e)
+{
+    if (!e)
+        return STEPTH_ERR_BAD_ARG;
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    e->stream = e->own_stream;
     return STEPTH_OK;
 }
 

@@ -39,7 +39,7 @@ def _describe(a, channels: Sequence[int], name: str) -> Tuple[L.Image, object]:
         t = a if a.dim() == 3 else a.unsqueeze(-1)
         if t.dim() != 3 or t.shape[2] not in channels:
             raise ValueError(f"{name}: shape {tuple(a.shape)} not [H,W,{list(channels)}]")
-        if t.stride(2) != 1 or t.stride(1) != t.shape[2]:
+        if (t.shape[2] > 1 and t.stride(2) != 1) or (t.shape[1] > 1 and t.stride(1) != t.shape[2]):
             raise ValueError(f"{name}: pixels must be contiguous within a row")
         im = L.Image(t.data_ptr(), t.shape[1], t.shape[0], t.shape[2], L.MEM_DEVICE,
                      t.stride(0) if t.shape[0] > 1 else t.shape[1] * t.shape[2])
@@ -50,7 +50,8 @@ def _describe(a, channels: Sequence[int], name: str) -> Tuple[L.Image, object]:
     v = arr if arr.ndim == 3 else arr[..., None]
     if v.ndim != 3 or v.shape[2] not in channels:
         raise ValueError(f"{name}: shape {arr.shape} not [H,W,{list(channels)}]")
-    if v.shape[0] and v.shape[1] and (v.strides[2] != 1 or v.strides[1] != v.shape[2]):
+    if ((v.shape[2] > 1 and v.strides[2] != 1) or
+            (v.shape[1] > 1 and v.strides[1] != v.shape[2])):
         raise ValueError(f"{name}: pixels must be contiguous within a row")
     stride = v.strides[0] if v.shape[0] > 1 else v.shape[1] * v.shape[2]
     im = L.Image(v.ctypes.data, v.shape[1], v.shape[0], v.shape[2], L.MEM_HOST, stride)
@@ -104,8 +105,13 @@ class Engine:
             self._lib.stepth_status_string(st).decode()
         raise (MaxZeroError if st == L.ERR_MAX_ZERO else StepthError)(st, msg)
 
-    def set_stream(self, hip_stream: Optional[int]):
-        self._check(self._lib.stepth_engine_set_stream(self._h, hip_stream))
+    def set_stream(self, hip_stream: int):
+        """Run on this hipStream_t handle (0 = HIP's default stream)."""
+        self._check(self._lib.stepth_engine_set_stream(self._h, hip_stream or None))
+
+    def reset_stream(self):
+        """Back to the engine's own non-blocking stream."""
+        self._check(self._lib.stepth_engine_reset_stream(self._h))
 
     def use_torch_stream(self):
         import torch
