@@ -40,7 +40,7 @@ struct stepth_engine {
     hipStream_t stream = nullptr;
     std::string err;
 
-    DevBuf P, PT;          // packed additional image (rows / columns)
+    DevBuf T, BB;          // packed additional image: tiled cells, block bounds
     DevBuf stage_main, stage_add, stage_out, stage_groups;
     DevBuf queries, raw, aux32, aux_pos, aux_found;
     DevBuf sad_left, sad_right;
@@ -168,19 +168,19 @@ struct KernelTimer { // brackets the dominant kernel with events when timing is 
     }
 };
 
-inline uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
 
-// RGB8 additional image -> P / PT planes (src/depth_image.rs:96-100)
+// RGB8 additional image -> tiled cells T + block bounds BB (src/depth_image.rs:96-100)
 int pack_additional(stepth_engine *e, const uint8_t *d_add, size_t stride, uint32_t wa,
-                    uint32_t ha, uint32_t &wp, uint32_t &hp)
+                    uint32_t ha, uint32_t &bw, uint32_t &bh)
 {
-    wp = round_up(wa, 64);
-    hp = round_up(ha, 64);
-    TRY(reserve(e, e->P, (size_t)ha * wp * 4));
-    TRY(reserve(e, e->PT, (size_t)wa * hp * 4));
-    PackArgs pa{d_add, stride, wa, ha, wp, hp, (uint32_t *)e->P.p, (uint32_t *)e->PT.p};
-    dim3 grid(wp / 32, hp / 32);
-    hipLaunchKernelGGL(pack_additional_kernel, grid, dim3(256), 0, e->stream, pa);
+    bw = (wa + 7u) / 8u;
+    bh = (ha + 7u) / 8u;
+    const size_t nblk = (size_t)bw * bh;
+    TRY(reserve(e, e->T, nblk * 64 * 4));
+    TRY(reserve(e, e->BB, nblk * 8));
+    PackArgs pa{d_add, stride, wa, ha, bw, bh, (uint32_t *)e->T.p, (uint2 *)e->BB.p};
+    hipLaunchKernelGGL(pack_additional_kernel, dim3((uint32_t)((nblk + 3) / 4)), dim3(256), 0,
+                       e->stream, pa);
     HIP_TRY(e, hipGetLastError());
     return STEPTH_OK;
 }
@@ -264,7 +264,7 @@ void stepth_engine_destroy(stepth_engine *e)
         return;
     (void)hipSetDevice(e->device);
     (void)hipStreamSynchronize(e->stream);
-    for (DevBuf *b : {&e->P, &e->PT, &e->stage_main, &e->stage_add, &e->stage_out,
+    for (DevBuf *b : {&e->T, &e->BB, &e->stage_main, &e->stage_add, &e->stage_out,
                       &e->stage_groups, &e->queries, &e->raw, &e->aux32, &e->aux_pos,
                       &e->aux_found, &e->sad_left, &e->sad_right})
         release(*b);
@@ -410,16 +410,16 @@ int stepth_depth_from_additional(stepth_engine *e, const stepth_image *main_im,
             HIP_TRY(e, hipGetLastError());
         }
     } else if (p.mode == STEPTH_MODE_RING_FIRST_HIT) {
-        uint32_t wp = 0, hp = 0;
-        TRY(pack_additional(e, d_add, as, add_im->width, add_im->height, wp, hp));
+        uint32_t bw = 0, bh = 0;
+        TRY(pack_additional(e, d_add, as, add_im->width, add_im->height, bw, bh));
 
         RingArgs ra{};
-        ra.P = (const uint32_t *)e->P.p;
-        ra.PT = (const uint32_t *)e->PT.p;
+        ra.T = (const uint32_t *)e->T.p;
+        ra.BB = (const uint2 *)e->BB.p;
         ra.wa = add_im->width;
         ra.ha = add_im->height;
-        ra.wp = wp;
-        ra.hp = hp;
+        ra.bw = bw;
+        ra.bh = bh;
         ra.max_steps = p.max_steps;
         memcpy(ra.prec, p.precision, 3);
         ra.max_word = e->words;
@@ -634,8 +634,8 @@ int stepth_distance_dot_array_batch(stepth_engine *e, const stepth_image *array,
     const uint8_t *d_add = nullptr;
     size_t as = 0;
     TRY(to_device(e, *array, e->stage_add, d_add, as));
-    uint32_t wp = 0, hp = 0;
-    TRY(pack_additional(e, d_add, as, array->width, array->height, wp, hp));
+    uint32_t bw = 0, bh = 0;
+    TRY(pack_additional(e, d_add, as, array->width, array->height, bw, bh));
 
     std::vector<Query> qs(n);
     for (size_t i = 0; i < n; ++i) {
@@ -652,12 +652,12 @@ int stepth_distance_dot_array_batch(stepth_engine *e, const stepth_image *array,
                               e->stream));
     hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(64), 0, e->stream, e->words, 2);
     RingArgs ra{};
-    ra.P = (const uint32_t *)e->P.p;
-    ra.PT = (const uint32_t *)e->PT.p;
+    ra.T = (const uint32_t *)e->T.p;
+    ra.BB = (const uint2 *)e->BB.p;
     ra.wa = array->width;
     ra.ha = array->height;
-    ra.wp = wp;
-    ra.hp = hp;
+    ra.bw = bw;
+    ra.bh = bh;
     ra.queries = (const Query *)e->queries.p;
     ra.n = (uint32_t)n;
     ra.max_steps = max;

@@ -12,44 +12,70 @@
 namespace stepth {
 
 // ---------------------------------------------------------------------------------------
-// pack_additional: RGB8 [Ha][Wa] -> P [Ha][Wp] dwords (row image) and PT [Wa][Hp] dwords
-// (column image = transpose), both in the cell format of cell_pack.h, pitch-padded with
-// kNoCell.  Replaces disage::converters::raw_rgb + pixels_to_array
-// (src/depth_image.rs:97-100): the Vec<Vec<[u8;3]>> becomes two flat dword planes so that
-// BOTH the row sides and the column sides of a ring (helpers.rs:28-31) are unit-stride reads.
+// pack_additional: RGB8 [Ha][Wa] -> the search structure in HBM.  Replaces
+// disage::converters::raw_rgb + pixels_to_array (src/depth_image.rs:97-100): instead of a
+// Vec<Vec<[u8;3]>> the additional image becomes
+//
+//   T  [bh][bw][8][8] dwords  cells (cell_pack.h) tiled in 8x8 blocks, one block = 256
+//                             contiguous bytes = one fully coalesced wave read; cells of
+//                             edge blocks that fall outside the image are kNoCell
+//   BB [bh][bw] uint2         per-block channel bounds {max, min} in the same spread format
+//
+// with bw = ceil(Wa/8), bh = ceil(Ha/8).  One wave packs one block.
 // ---------------------------------------------------------------------------------------
+constexpr int kBlk = 8;       // block side
+constexpr int kBlkShift = 3;
+
 struct PackArgs {
     const uint8_t *src;
     size_t stride;
     uint32_t wa, ha;
-    uint32_t wp, hp; // pitches in dwords
-    uint32_t *P, *PT;
+    uint32_t bw, bh;
+    uint32_t *T;
+    uint2 *BB;
 };
+
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        v = min(v, (uint32_t)__shfl_xor((int)v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        v = max(v, (uint32_t)__shfl_xor((int)v, o, 64));
+    return v;
+}
 
 __global__ __launch_bounds__(256) void pack_additional_kernel(PackArgs a)
 {
-    __shared__ uint32_t tile[32][33];
-    const uint32_t tx = threadIdx.x & 31, ty = threadIdx.x >> 5; // 32 x 8
-    const uint32_t x0 = blockIdx.x * 32, y0 = blockIdx.y * 32;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const uint32_t y = y0 + ty + 8 * r, x = x0 + tx;
-        uint32_t cell = kNoCell;
-        if (y < a.ha && x < a.wa) {
-            const uint8_t *p = a.src + (size_t)y * a.stride + (size_t)x * 3;
-            cell = pack_cell(p[0], p[1], p[2]);
-        }
-        if (y < a.ha && x < a.wp)
-            a.P[(size_t)y * a.wp + x] = cell;
-        tile[ty + 8 * r][tx] = cell;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t blk = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (blk >= a.bw * a.bh)
+        return;
+    const uint32_t bx = blk % a.bw, by = blk / a.bw;
+    const uint32_t x = bx * kBlk + (lane & 7u), y = by * kBlk + (lane >> 3);
+    uint32_t cell = kNoCell;
+    uint32_t mn[3] = {255u, 255u, 255u}, mx[3] = {0u, 0u, 0u};
+    if (x < a.wa && y < a.ha) {
+        const uint8_t *p = a.src + (size_t)y * a.stride + (size_t)x * 3;
+        mn[0] = mx[0] = p[0];
+        mn[1] = mx[1] = p[1];
+        mn[2] = mx[2] = p[2];
+        cell = pack_cell(p[0], p[1], p[2]);
     }
-    __syncthreads();
+    a.T[(size_t)blk * 64u + lane] = cell;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const uint32_t x = x0 + ty + 8 * r, y = y0 + tx; // transposed write, unit stride in y
-        if (x < a.wa && y < a.hp)
-            a.PT[(size_t)x * a.hp + y] = tile[tx][ty + 8 * r];
+    for (int c = 0; c < 3; ++c) {
+        mn[c] = wave_min_u32(mn[c]);
+        mx[c] = wave_max_u32(mx[c]);
     }
+    if (lane == 0)
+        a.BB[blk] = make_uint2(pack_cell(mx[0], mx[1], mx[2]), pack_cell(mn[0], mn[1], mn[2]));
 }
 
 // ---------------------------------------------------------------------------------------
@@ -132,23 +158,31 @@ __global__ __launch_bounds__(256) void prep_list_kernel(PrepArgs a)
 // ---------------------------------------------------------------------------------------
 // ring_match: PASS 1 (src/depth_image.rs:112-123) with helpers::distance_dot_array inlined.
 //
-// Work decomposition
-//   * one wave owns 64 consecutive queries; phase A tests every lane's ring 0 (its centre
-//     cell) -- on natural images most queries end here;
-//   * phase B serves the survivors one at a time with the WHOLE wave: the 64 lanes walk the
-//     ring sequence in the reference's scan order (row y+s, row y-s, column x+s, column x-s,
-//     each ascending -- helpers.rs:28-31), 64..128 consecutive cells per step, unit-stride
-//     from P (rows) or PT (columns).  `__ballot` of the box test + lowest set bit is the
-//     sequential loop's first hit, bit for bit; later cells of the step are simply ignored.
-//   * rings 1..7 (252 probes) are walked with a per-lane table of (dx,dy) offsets in scan
-//     order, so that small rings also fill all 64 lanes.
-// A ring search ends at the first ring with no in-bounds cell (helpers.rs:49-51), which for an
-// in-bounds centre is ring max(cx, Wa-1-cx, cy, Ha-1-cy)+1, and immediately (None) for a
-// centre outside the array.
+// The reference walks rings s = 0,1,2,.. around `middle` and, inside a ring, row y+s, row
+// y-s, column x+s, column x-s, each ascending (helpers.rs:26-31), and returns the first cell
+// inside the colour box.  Give every cell the key (s << 12) | position-in-that-scan: the
+// answer is the matching cell with the smallest key, so cells may be examined in ANY order
+// and most of them need not be examined at all:
+//
+//   * phase A: every lane tests its own query's centre cell (ring 0) -- on natural images
+//     a large share of the queries ends here;
+//   * phase B serves the survivors one at a time with the whole wave.  The 8x8 blocks around
+//     the centre block are visited in square block-rings (64 blocks per step, one lane
+//     each); a block whose channel bounds BB do not intersect the colour box cannot hold a
+//     match and is dropped after one 8-byte read -- 1/64 of the reference's probes.  Every
+//     surviving block costs one step: 64 lanes read its 64 cells (256 contiguous bytes),
+//     test them and keep the smallest key.
+//   * all cells of rings s <= 8 M lie in block-rings <= M, so once block-rings 0..M are
+//     done and the best key's ring is <= 8 M, no unvisited cell can beat it: stop.
+//
+// A ring search ends at the first ring with no in-bounds cell (helpers.rs:49-51): ring
+// max(cx, Wa-1-cx, cy, Ha-1-cy)+1 for an in-bounds centre, and immediately (None) for a
+// centre outside the array -- both folded into s_end.
 // ---------------------------------------------------------------------------------------
 struct RingArgs {
-    const uint32_t *P, *PT;
-    uint32_t wa, ha, wp, hp;
+    const uint32_t *T;
+    const uint2 *BB;
+    uint32_t wa, ha, bw, bh;
     // QMODE 0: one query per main pixel (uniform 1x1 tiles), read straight from the image
     const uint8_t *main_px;
     size_t mstride;
@@ -166,21 +200,46 @@ struct RingArgs {
     unsigned long long *stats; // optional [ring0_hits, probes]
 };
 
-constexpr int kLinRings = 8; // rings 1..kLinRings-1 use the offset table (4*8*8-4 = 252 probes)
+constexpr uint32_t kNoKey = 0xFFFFFFFFu;
 
 __device__ __forceinline__ uint32_t bcast(uint32_t v, int src_lane)
 {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, src_lane);
 }
 
-// offset table entry for linear probe index t (ring s starts at t = 4 s^2, 8s+4 probes)
-__device__ __forceinline__ void probe_offset(uint32_t t, int &dx, int &dy, int &s)
+// position of a cell in the reference's scan: ring s = max(|dx|,|dy|), then row y+s (dx
+// ascending), row y-s, column x+s (dy ascending), column x-s; a corner belongs to the row
+// that reaches it first (helpers.rs:28-31)
+__device__ __forceinline__ uint32_t scan_key(int dx, int dy, uint32_t &ring)
 {
-    s = (int)isqrt_floor(t >> 2);
-    const int r = (int)t - 4 * s * s, len = 2 * s + 1;
-    const int side = r / len, off = r - side * len - s;
-    dx = side == 0 ? off : side == 1 ? off : side == 2 ? s : -s;
+    const int s = max(abs(dx), abs(dy)), len = 2 * s + 1;
+    const int idx = dy == s ? dx + s : dy == -s ? len + dx + s : dx == s ? 2 * len + dy + s
+                                                                         : 3 * len + dy + s;
+    ring = (uint32_t)s;
+    return ((uint32_t)s << 12) | (uint32_t)idx;
+}
+
+__device__ __forceinline__ void key_to_offset(uint32_t key, int &dx, int &dy)
+{
+    const int s = (int)(key >> 12), idx = (int)(key & 0xFFFu), len = 2 * s + 1;
+    const int side = idx / len, off = idx - side * len - s;
+    dx = side < 2 ? off : side == 2 ? s : -s;
     dy = side == 0 ? s : side == 1 ? -s : off;
+}
+
+// slot u of the block spiral: block-ring m holds slots [(2m-1)^2, (2m+1)^2), walked as a
+// pinwheel of four sides of 2m blocks; slot 0 is the centre block
+__device__ __forceinline__ void block_slot(uint32_t u, int &i, int &j)
+{
+    if (u == 0) {
+        i = j = 0;
+        return;
+    }
+    const int m = (int)((isqrt_floor(u) + 1u) >> 1);
+    const int t = (int)u - (2 * m - 1) * (2 * m - 1);
+    const int side = t / (2 * m), o = t - side * 2 * m;
+    i = side == 0 ? -m + o : side == 1 ? m : side == 2 ? -m + 1 + o : -m;
+    j = side == 0 ? -m : side == 1 ? -m + o : side == 2 ? m : -m + 1 + o;
 }
 
 template <int QMODE, bool STATS>
@@ -212,17 +271,15 @@ __global__ __launch_bounds__(256) void ring_match_kernel(RingArgs a)
     // ---- phase A: ring 0, one lane per query ------------------------------------------
     const bool inb = valid && cx < a.wa && cy < a.ha && a.max_steps > 0;
     bool fnd = false;
-    uint32_t fx = 0, fy = 0;
+    int fdx = 0, fdy = 0;
     bool pending = false;
     if (inb) {
-        const uint32_t c = a.P[(size_t)cy * a.wp + cx];
-        if (cell_in_box(c, lo, hi)) {
+        const size_t blk = (size_t)(cy >> kBlkShift) * a.bw + (cx >> kBlkShift);
+        const uint32_t c = a.T[blk * 64u + ((cy & 7u) << 3) + (cx & 7u)];
+        if (cell_in_box(c, lo, hi))
             fnd = true;
-            fx = cx;
-            fy = cy;
-        } else {
+        else
             pending = a.max_steps > 1;
-        }
     }
     unsigned long long n_probe = 0;
     if constexpr (STATS)
@@ -231,113 +288,86 @@ __global__ __launch_bounds__(256) void ring_match_kernel(RingArgs a)
 
     // ---- phase B: survivors, whole wave per query ---------------------------------------
     unsigned long long pend = __ballot(pending);
-    if (pend) {
-        // scan-order offsets of probes 4..259 (rings 1..7), 4 per lane
-        int odx[4], ody[4], os[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            probe_offset(4u + 64u * k + lane, odx[k], ody[k], os[k]);
+    const int lx = (int)(lane & 7u), ly = (int)(lane >> 3);
+    while (pend) {
+        const int src = __ffsll(pend) - 1;
+        pend &= pend - 1;
+        const uint32_t qx = bcast(cx, src), qy = bcast(cy, src);
+        const uint32_t qlo = bcast(lo, src), qhi = bcast(hi, src);
+        const uint32_t smax = max(max(qx, a.wa - 1u - qx), max(qy, a.ha - 1u - qy));
+        const uint32_t s_end = min(a.max_steps, smax + 1u); // rings 0..s_end-1 are searched
+        const int cbx = (int)(qx >> kBlkShift), cby = (int)(qy >> kBlkShift);
+        const int ox = (int)(qx & 7u), oy = (int)(qy & 7u);
+        const uint32_t m_end = (s_end + 6u) >> 3;             // last block-ring with ring < s_end
+        const uint32_t u_end = (2u * m_end + 1u) * (2u * m_end + 1u);
 
-        while (pend) {
-            const int src = __ffsll(pend) - 1;
-            pend &= pend - 1;
-            const uint32_t qx = bcast(cx, src), qy = bcast(cy, src);
-            const uint32_t qlo = bcast(lo, src), qhi = bcast(hi, src);
-            const uint32_t smax = max(max(qx, a.wa - 1u - qx), max(qy, a.ha - 1u - qy));
-            const uint32_t s_end = min(a.max_steps, smax + 1u);
-            bool hit = false;
-            uint32_t hx = 0, hy = 0;
-
-            // rings 1..7 through the offset table
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (hit || (uint32_t)(k == 0 ? 1 : k == 1 ? 4 : k == 2 ? 5 : 7) >= s_end)
-                    break; // first ring of this step: probes 4,68,132,196 -> rings 1,4,5,7
-                const uint32_t px = qx + (uint32_t)odx[k], py = qy + (uint32_t)ody[k];
-                // probes 256..259 of the table belong to ring 8, which the side loop covers
-                const bool act = (uint32_t)os[k] < min(s_end, (uint32_t)kLinRings) &&
-                                 px < a.wa && py < a.ha;
-                const uint32_t c = act ? a.P[(size_t)py * a.wp + px] : kNoCell;
-                const unsigned long long m = __ballot(cell_in_box(c, qlo, qhi));
-                if constexpr (STATS)
-                    n_probe += __popcll(__ballot(act));
-                if (m) {
-                    const int w = __ffsll(m) - 1;
-                    hx = bcast(px, w);
-                    hy = bcast(py, w);
-                    hit = true;
-                }
+        uint32_t best = kNoKey;      // wave-uniform best key so far
+        uint32_t best_ring = s_end;  // blocks farther than this cannot improve `best`
+        for (uint32_t u0 = 0; u0 < u_end; u0 += 64u) {
+            // -- one step of block tests: 64 slots of the spiral --
+            int bi, bj;
+            block_slot(u0 + lane, bi, bj);
+            const int bx = cbx + bi, by = cby + bj;
+            // smallest ring index of any cell of this block
+            const int ddx = bi > 0 ? 8 * bi - ox : bi < 0 ? ox - 8 * bi - 7 : 0;
+            const int ddy = bj > 0 ? 8 * bj - oy : bj < 0 ? oy - 8 * bj - 7 : 0;
+            const uint32_t dmin = (uint32_t)max(ddx, ddy);
+            bool cand = u0 + lane < u_end && bx >= 0 && by >= 0 && bx < (int)a.bw &&
+                        by < (int)a.bh && dmin < best_ring + (best == kNoKey ? 0u : 1u);
+            if (cand) {
+                const uint2 bb = a.BB[(size_t)by * a.bw + bx];
+                // box [lo,hi] meets [bmin,bmax] on every channel
+                cand = (((bb.x - qlo) & (qhi - bb.y)) | ~kGuard) == 0xFFFFFFFFu;
             }
+            unsigned long long pm = __ballot(cand);
+            if constexpr (STATS)
+                n_probe += __popcll(pm) * 64ull + 64ull;
 
-            // rings >= 8: four unit-stride sides per ring
-            for (uint32_t s = kLinRings; s < s_end && !hit; ++s) {
-#pragma unroll
-                for (int side = 0; side < 4 && !hit; ++side) {
-                    const bool rowside = side < 2;
-                    const uint32_t line = rowside ? (side == 0 ? qy + s : qy - s)
-                                                  : (side == 2 ? qx + s : qx - s);
-                    const uint32_t nline = rowside ? a.ha : a.wa;
-                    if (line >= nline) // also catches the unsigned wrap of qy - s < 0
-                        continue;
-                    const uint32_t *base = rowside ? a.P + (size_t)line * a.wp
-                                                   : a.PT + (size_t)line * a.hp;
-                    const uint32_t cen = rowside ? qx : qy;
-                    const uint32_t lim = rowside ? a.wa : a.ha;
-                    const uint32_t j0 = cen >= s ? cen - s : 0u;
-                    const uint32_t j1 = min(cen + s, lim - 1u); // inclusive
-                    for (uint32_t jb = j0; jb <= j1; jb += 128u) {
-                        const uint32_t ja = jb + lane, jc = ja + 64u;
-                        const uint32_t ca = ja <= j1 ? base[ja] : kNoCell;
-                        const uint32_t cb = jc <= j1 ? base[jc] : kNoCell;
-                        if constexpr (STATS)
-                            n_probe += min(j1 - jb + 1u, 128u);
-                        unsigned long long m = __ballot(cell_in_box(ca, qlo, qhi));
-                        uint32_t jh = jb;
-                        if (!m) {
-                            m = __ballot(cell_in_box(cb, qlo, qhi));
-                            jh = jb + 64u;
-                        }
-                        if (m) {
-                            jh += (uint32_t)(__ffsll(m) - 1);
-                            hx = rowside ? jh : line;
-                            hy = rowside ? line : jh;
-                            hit = true;
-                            break;
-                        }
-                    }
-                }
+            // -- one step per surviving block: its 64 cells --
+            uint32_t mine = kNoKey;
+            while (pm) {
+                const int b = __ffsll(pm) - 1;
+                pm &= pm - 1;
+                const int sbx = (int)bcast((uint32_t)bx, b), sby = (int)bcast((uint32_t)by, b);
+                const uint32_t c = a.T[((size_t)sby * a.bw + sbx) * 64u + lane];
+                uint32_t ring;
+                const uint32_t key = scan_key(sbx * 8 + lx - (int)qx, sby * 8 + ly - (int)qy, ring);
+                if (cell_in_box(c, qlo, qhi) && ring < s_end)
+                    mine = min(mine, key);
             }
-
-            if ((int)lane == src && hit) {
-                fnd = true;
-                fx = hx;
-                fy = hy;
+            if (__ballot(mine != kNoKey)) {
+                best = min(best, wave_min_u32(mine));
+                best_ring = best >> 12;
             }
+            // block-rings 0..m_done are complete after this step
+            const uint32_t done = min(u0 + 64u, u_end);
+            const uint32_t m_done = (isqrt_floor(done) - 1u) >> 1;
+            if (best != kNoKey && best_ring <= 8u * m_done)
+                break;
+        }
+        if ((int)lane == src && best != kNoKey) {
+            fnd = true;
+            key_to_offset(best, fdx, fdy);
         }
     }
 
     // ---- epilogue: distance (helpers.rs:3-7), u8 wrap (depth_image.rs:121), max (:124) ----
     uint32_t d = 0;
-    if (fnd) {
-        const int dx = (int)fx - (int)cx, dy = (int)fy - (int)cy;
-        d = isqrt_floor((uint32_t)(dx * dx + dy * dy));
-    }
+    if (fnd)
+        d = isqrt_floor((uint32_t)(fdx * fdx + fdy * fdy));
     const uint32_t d8 = d & 0xffu;
     if (valid) {
         a.raw[q] = (uint8_t)d8;
         if (a.raw32)
             a.raw32[q] = d;
         if (a.pos) {
-            a.pos[2 * (size_t)q] = fnd ? fx : 0u;
-            a.pos[2 * (size_t)q + 1] = fnd ? fy : 0u;
+            a.pos[2 * (size_t)q] = fnd ? (uint32_t)((int)cx + fdx) : 0u;
+            a.pos[2 * (size_t)q + 1] = fnd ? (uint32_t)((int)cy + fdy) : 0u;
         }
         if (a.found)
             a.found[q] = fnd ? 1 : 0;
     }
-    uint32_t m = valid ? d8 : 0u;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-        m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+    const uint32_t m = wave_max_u32(valid ? d8 : 0u);
     if (lane == 0) {
         if (m)
             atomicMax(a.max_word, m);
