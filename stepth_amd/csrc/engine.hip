@@ -46,6 +46,7 @@ struct stepth_engine {
     DevBuf sad_left, sad_right;
     uint32_t *words = nullptr; // [0] max, [1] scratch max (host-visible copy target), [2..3] pad
     unsigned long long *stats = nullptr; // [ring0_hits, probes]
+    uint32_t *spiral = nullptr;          // block-spiral table + per-chunk complete rings
     uint64_t stats_groups = 0;
     bool stats_enabled = false;
 
@@ -190,6 +191,8 @@ int launch_ring(stepth_engine *e, RingArgs &ra, int qmode)
     if (ra.n == 0)
         return STEPTH_OK;
     const uint32_t blocks = (ra.n + 255u) / 256u;
+    ra.spiral = e->spiral;
+    ra.spiral_done = e->spiral + kSpiralChunks * 64;
     KernelTimer t(e);
     if (e->stats_enabled) {
         ra.stats = e->stats;
@@ -254,6 +257,22 @@ int stepth_engine_create(int device_id, stepth_engine **out)
     e->stream = e->own_stream;
     (void)hipMemsetAsync(e->words, 0, 64, e->stream);
     (void)hipMemsetAsync(e->stats, 0, 64, e->stream);
+    {
+        // block-spiral table of ring_match_kernel (query independent)
+        std::vector<uint32_t> tab((kSpiralChunks * 64) + kSpiralChunks, 0u);
+        for (uint32_t u = 0; u < kSpiralChunks * 64; ++u) {
+            int bi = 0, bj = 0;
+            block_slot(u, bi, bj);
+            tab[u] = ((uint32_t)bi & 0xffffu) | ((uint32_t)bj << 16);
+        }
+        for (uint32_t k = 0; k < kSpiralChunks; ++k)
+            tab[kSpiralChunks * 64 + k] = rings_done(64u * (k + 1));
+        if (hipMalloc((void **)&e->spiral, tab.size() * 4) != hipSuccess ||
+            hipMemcpy(e->spiral, tab.data(), tab.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+            stepth_engine_destroy(e);
+            return STEPTH_ERR_HIP;
+        }
+    }
     *out = e;
     return STEPTH_OK;
 }
@@ -272,6 +291,8 @@ void stepth_engine_destroy(stepth_engine *e)
         (void)hipFree(e->words);
     if (e->stats)
         (void)hipFree(e->stats);
+    if (e->spiral)
+        (void)hipFree(e->spiral);
     for (auto &ev : e->events) {
         (void)hipEventDestroy(ev.first);
         (void)hipEventDestroy(ev.second);

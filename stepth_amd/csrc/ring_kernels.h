@@ -198,6 +198,8 @@ struct RingArgs {
     uint8_t *found;    // optional: Some/None
     uint32_t *max_word; // atomicMax of raw, depth_image.rs:124
     unsigned long long *stats; // optional [ring0_hits, probes]
+    const uint32_t *spiral;      // kSpiralChunks*64 block-spiral slots (host-built)
+    const uint32_t *spiral_done; // kSpiralChunks: complete block-rings after chunk k
 };
 
 constexpr uint32_t kNoKey = 0xFFFFFFFFu;
@@ -207,29 +209,48 @@ __device__ __forceinline__ uint32_t bcast(uint32_t v, int src_lane)
     return (uint32_t)__builtin_amdgcn_readlane((int)v, src_lane);
 }
 
-// position of a cell in the reference's scan: ring s = max(|dx|,|dy|), then row y+s (dx
-// ascending), row y-s, column x+s (dy ascending), column x-s; a corner belongs to the row
-// that reaches it first (helpers.rs:28-31)
+// wave-wide unsigned min in 4 DPP steps + 4 readlanes (no LDS crossbar):
+// quad xor 1, quad xor 2, row rotate 4, row rotate 8 leave every 16-lane row reduced.
+__device__ __forceinline__ uint32_t wave_min_dpp(uint32_t v)
+{
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x124, 0xF, 0xF, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x128, 0xF, 0xF, false));
+    return min(min(bcast(v, 0), bcast(v, 16)), min(bcast(v, 32), bcast(v, 48)));
+}
+
+// Order-preserving key of a cell in the reference's scan (helpers.rs:26-31): ring
+// s = max(|dx|,|dy|) first, then the side (row y+s, row y-s, column x+s, column x-s), then
+// the position along that side (ascending).  A corner belongs to the row that reaches it
+// first.  Bits: s [19:11], side [10:9], position [8:0] (position <= 2*254).
 __device__ __forceinline__ uint32_t scan_key(int dx, int dy, uint32_t &ring)
 {
-    const int s = max(abs(dx), abs(dy)), len = 2 * s + 1;
-    const int idx = dy == s ? dx + s : dy == -s ? len + dx + s : dx == s ? 2 * len + dy + s
-                                                                         : 3 * len + dy + s;
+    const int ndx = -dx, ndy = -dy;
+    const int s = max(max(dx, ndx), max(dy, ndy));
+    const bool top = dy == s, bot = ndy == s;
+    const uint32_t side = top ? 0u : bot ? 1u : dx == s ? 2u : 3u;
+    const int pos = ((top || bot) ? dx : dy) + s;
     ring = (uint32_t)s;
-    return ((uint32_t)s << 12) | (uint32_t)idx;
+    return ((uint32_t)s << 11) | (side << 9) | (uint32_t)pos;
 }
 
 __device__ __forceinline__ void key_to_offset(uint32_t key, int &dx, int &dy)
 {
-    const int s = (int)(key >> 12), idx = (int)(key & 0xFFFu), len = 2 * s + 1;
-    const int side = idx / len, off = idx - side * len - s;
+    const int s = (int)(key >> 11), side = (int)((key >> 9) & 3u), off = (int)(key & 511u) - s;
     dx = side < 2 ? off : side == 2 ? s : -s;
     dy = side == 0 ? s : side == 1 ? -s : off;
 }
 
-// slot u of the block spiral: block-ring m holds slots [(2m-1)^2, (2m+1)^2), walked as a
-// pinwheel of four sides of 2m blocks; slot 0 is the centre block
-__device__ __forceinline__ void block_slot(uint32_t u, int &i, int &j)
+// Block spiral: slot u -> block offset (bi, bj) from the centre block.  Block-ring m holds
+// slots [(2m-1)^2, (2m+1)^2), walked as a pinwheel of four sides of 2m blocks; slot 0 is the
+// centre block.  The first kSpiralSlots slots come from a host-built table staged in LDS
+// (entry = (bi & 0xffff) | (bj << 16)); anything beyond (max_steps > 264) is computed.
+constexpr uint32_t kSpiralRings = 33;                                   // block-rings 0..33
+constexpr uint32_t kSpiralSlots = (2 * kSpiralRings + 1) * (2 * kSpiralRings + 1); // 4489
+constexpr uint32_t kSpiralChunks = (kSpiralSlots + 63) / 64;            // 71
+
+STEPTH_HD void block_slot(uint32_t u, int &i, int &j)
 {
     if (u == 0) {
         i = j = 0;
@@ -242,9 +263,25 @@ __device__ __forceinline__ void block_slot(uint32_t u, int &i, int &j)
     j = side == 0 ? -m : side == 1 ? -m + o : side == 2 ? m : -m + 1 + o;
 }
 
+// number of complete block-rings once slots [0, done) are processed: largest m with
+// (2m+1)^2 <= done
+STEPTH_HD uint32_t rings_done(uint32_t done) { return (isqrt_floor(done) - 1u) >> 1; }
+
 template <int QMODE, bool STATS>
 __global__ __launch_bounds__(256) void ring_match_kernel(RingArgs a)
 {
+    __shared__ uint32_t s_spiral[kSpiralChunks * 64];
+    __shared__ uint32_t s_done[kSpiralChunks];
+    {
+        // stage the part of the spiral this launch can reach
+        const uint32_t m_cap = min((min(a.max_steps, 0x10000u) + 6u) >> 3, kSpiralRings);
+        const uint32_t need = min((2u * m_cap + 1u) * (2u * m_cap + 1u), kSpiralChunks * 64u);
+        for (uint32_t i = threadIdx.x; i < need; i += blockDim.x)
+            s_spiral[i] = a.spiral[i];
+        for (uint32_t i = threadIdx.x; i < kSpiralChunks; i += blockDim.x)
+            s_done[i] = a.spiral_done[i];
+        __syncthreads();
+    }
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);
     const uint32_t q = wave * 64u + lane;
@@ -297,25 +334,32 @@ __global__ __launch_bounds__(256) void ring_match_kernel(RingArgs a)
         const uint32_t smax = max(max(qx, a.wa - 1u - qx), max(qy, a.ha - 1u - qy));
         const uint32_t s_end = min(a.max_steps, smax + 1u); // rings 0..s_end-1 are searched
         const int cbx = (int)(qx >> kBlkShift), cby = (int)(qy >> kBlkShift);
-        const int ox = (int)(qx & 7u), oy = (int)(qy & 7u);
+        const int nox = -(int)(qx & 7u), noy = -(int)(qy & 7u);
         const uint32_t m_end = (s_end + 6u) >> 3;             // last block-ring with ring < s_end
         const uint32_t u_end = (2u * m_end + 1u) * (2u * m_end + 1u);
-
-        uint32_t best = kNoKey;      // wave-uniform best key so far
-        uint32_t best_ring = s_end;  // blocks farther than this cannot improve `best`
-        for (uint32_t u0 = 0; u0 < u_end; u0 += 64u) {
-            // -- one step of block tests: 64 slots of the spiral --
+        const int rx = cbx * 8 - (int)qx + lx, ry = cby * 8 - (int)qy + ly; // lane's cell offset
+                                                                            // inside block (0,0)
+        uint32_t best = kNoKey;  // wave-uniform best key so far
+        uint32_t limit = s_end;  // a block whose nearest cell is at ring >= limit is useless
+        for (uint32_t u0 = 0, k = 0; u0 < u_end; u0 += 64u, ++k) {
+            // -- one step of block tests: 64 slots of the spiral, one lane each --
             int bi, bj;
-            block_slot(u0 + lane, bi, bj);
+            if (k < kSpiralChunks) {
+                const uint32_t e = s_spiral[u0 + lane];
+                bi = (int)(short)(e & 0xffffu);
+                bj = (int)e >> 16;
+            } else {
+                block_slot(u0 + lane, bi, bj);
+            }
             const int bx = cbx + bi, by = cby + bj;
-            // smallest ring index of any cell of this block
-            const int ddx = bi > 0 ? 8 * bi - ox : bi < 0 ? ox - 8 * bi - 7 : 0;
-            const int ddy = bj > 0 ? 8 * bj - oy : bj < 0 ? oy - 8 * bj - 7 : 0;
-            const uint32_t dmin = (uint32_t)max(ddx, ddy);
-            bool cand = u0 + lane < u_end && bx >= 0 && by >= 0 && bx < (int)a.bw &&
-                        by < (int)a.bh && dmin < best_ring + (best == kNoKey ? 0u : 1u);
+            // smallest ring index of any cell of this block: max over axes of
+            // max(8b - o, o - 8b - 7, 0)
+            const int ax = (bi << 3) + nox, ay = (bj << 3) + noy;
+            const int dmin = max(max(max(ax, -7 - ax), max(ay, -7 - ay)), 0);
+            bool cand = u0 + lane < u_end && (uint32_t)bx < a.bw && (uint32_t)by < a.bh &&
+                        (uint32_t)dmin < limit;
             if (cand) {
-                const uint2 bb = a.BB[(size_t)by * a.bw + bx];
+                const uint2 bb = a.BB[(uint32_t)by * a.bw + (uint32_t)bx];
                 // box [lo,hi] meets [bmin,bmax] on every channel
                 cand = (((bb.x - qlo) & (qhi - bb.y)) | ~kGuard) == 0xFFFFFFFFu;
             }
@@ -323,26 +367,31 @@ __global__ __launch_bounds__(256) void ring_match_kernel(RingArgs a)
             if constexpr (STATS)
                 n_probe += __popcll(pm) * 64ull + 64ull;
 
-            // -- one step per surviving block: its 64 cells --
+            // -- one step per surviving block: its 64 cells (256 contiguous bytes) --
             uint32_t mine = kNoKey;
             while (pm) {
                 const int b = __ffsll(pm) - 1;
                 pm &= pm - 1;
-                const int sbx = (int)bcast((uint32_t)bx, b), sby = (int)bcast((uint32_t)by, b);
-                const uint32_t c = a.T[((size_t)sby * a.bw + sbx) * 64u + lane];
-                uint32_t ring;
-                const uint32_t key = scan_key(sbx * 8 + lx - (int)qx, sby * 8 + ly - (int)qy, ring);
-                if (cell_in_box(c, qlo, qhi) && ring < s_end)
-                    mine = min(mine, key);
+                const int sbi = (int)bcast((uint32_t)bi, b), sbj = (int)bcast((uint32_t)bj, b);
+                const uint32_t sblk = (uint32_t)(cby + sbj) * a.bw + (uint32_t)(cbx + sbi);
+                const uint32_t c = a.T[(size_t)sblk * 64u + lane];
+                const bool hit = cell_in_box(c, qlo, qhi);
+                if (__ballot(hit)) { // keys only when some cell of the block matched
+                    uint32_t ring;
+                    const uint32_t key = scan_key(sbi * 8 + rx, sbj * 8 + ry, ring);
+                    if (hit && ring < s_end)
+                        mine = min(mine, key);
+                }
             }
             if (__ballot(mine != kNoKey)) {
-                best = min(best, wave_min_u32(mine));
-                best_ring = best >> 12;
+                best = min(best, wave_min_dpp(mine));
+                limit = min(limit, (best >> 11) + 1u);
             }
-            // block-rings 0..m_done are complete after this step
-            const uint32_t done = min(u0 + 64u, u_end);
-            const uint32_t m_done = (isqrt_floor(done) - 1u) >> 1;
-            if (best != kNoKey && best_ring <= 8u * m_done)
+            // block-rings 0..m_done are complete after this step: every cell of rings
+            // <= 8 m_done has been seen or excluded
+            const uint32_t m_done = k < kSpiralChunks ? s_done[k]
+                                                      : rings_done(min(u0 + 64u, u_end));
+            if (best != kNoKey && (best >> 11) <= 8u * m_done)
                 break;
         }
         if ((int)lane == src && best != kNoKey) {
