@@ -46,7 +46,8 @@ struct stepth_engine {
     DevBuf sad_left, sad_right;
     uint32_t *words = nullptr; // [0] max, [1] scratch max (host-visible copy target), [2..3] pad
     unsigned long long *stats = nullptr; // [ring0_hits, probes]
-    uint32_t *spiral = nullptr;          // block-spiral table + per-chunk complete rings
+    DevBuf spiral;                       // block-spiral table + per-chunk complete rings
+    uint32_t spiral_chunks = 0;
     uint64_t stats_groups = 0;
     bool stats_enabled = false;
 
@@ -186,13 +187,54 @@ int pack_additional(stepth_engine *e, const uint8_t *d_add, size_t stride, uint3
     return STEPTH_OK;
 }
 
+// Block-spiral table of ring_match_kernel (query independent): enough chunks for the rings a
+// search of `max_steps` steps can reach in an array of wa x ha cells.
+int ensure_spiral(stepth_engine *e, uint32_t max_steps, uint32_t wa, uint32_t ha)
+{
+    const uint32_t s_cap = std::min(max_steps, std::max(wa, ha));
+    const uint32_t m_cap = (s_cap + 6u) >> 3;
+    const uint64_t slots = (uint64_t)(2 * m_cap + 1) * (2 * m_cap + 1);
+    const uint32_t chunks = std::max<uint32_t>((uint32_t)((slots + 63) / 64), kSpiralChunks);
+    if (chunks <= e->spiral_chunks)
+        return STEPTH_OK;
+    std::vector<uint32_t> tab((size_t)chunks * 65, 0u);
+    for (uint32_t u = 0; u < chunks * 64; ++u) {
+        int bi = 0, bj = 0;
+        block_slot(u, bi, bj);
+        tab[u] = ((uint32_t)bi & 0xffffu) | ((uint32_t)bj << 16);
+    }
+    for (uint32_t k = 0; k < chunks; ++k)
+        tab[(size_t)chunks * 64 + k] = rings_done(64u * (k + 1));
+    TRY(reserve(e, e->spiral, tab.size() * 4));
+    HIP_TRY(e, hipMemcpyAsync(e->spiral.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice,
+                              e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream)); // `tab` dies at return
+    e->spiral_chunks = chunks;
+    return STEPTH_OK;
+}
+
 int launch_ring(stepth_engine *e, RingArgs &ra, int qmode)
 {
     if (ra.n == 0)
         return STEPTH_OK;
     const uint32_t blocks = (ra.n + 255u) / 256u;
-    ra.spiral = e->spiral;
-    ra.spiral_done = e->spiral + kSpiralChunks * 64;
+    TRY(ensure_spiral(e, ra.max_steps, ra.wa, ra.ha));
+    {
+        // 32-bit scan keys: ring | side(2) | position; sized for the farthest reachable ring
+        const uint32_t top = std::max(std::min(ra.max_steps, std::max(ra.wa, ra.ha)), 2u) - 1u;
+        uint32_t pb = 1, rb = 1;
+        while ((2u * top) >> pb)
+            ++pb;
+        while (top >> rb)
+            ++rb;
+        if (pb + 2u + rb > 32u)
+            return fail(e, STEPTH_ERR_BAD_ARG,
+                        "max_steps %u on a %ux%u array needs rings beyond 16383: unsupported",
+                        ra.max_steps, ra.wa, ra.ha);
+        ra.pos_bits = pb;
+    }
+    ra.spiral = (const uint32_t *)e->spiral.p;
+    ra.spiral_done = ra.spiral + (size_t)e->spiral_chunks * 64;
     KernelTimer t(e);
     if (e->stats_enabled) {
         ra.stats = e->stats;
@@ -257,22 +299,6 @@ int stepth_engine_create(int device_id, stepth_engine **out)
     e->stream = e->own_stream;
     (void)hipMemsetAsync(e->words, 0, 64, e->stream);
     (void)hipMemsetAsync(e->stats, 0, 64, e->stream);
-    {
-        // block-spiral table of ring_match_kernel (query independent)
-        std::vector<uint32_t> tab((kSpiralChunks * 64) + kSpiralChunks, 0u);
-        for (uint32_t u = 0; u < kSpiralChunks * 64; ++u) {
-            int bi = 0, bj = 0;
-            block_slot(u, bi, bj);
-            tab[u] = ((uint32_t)bi & 0xffffu) | ((uint32_t)bj << 16);
-        }
-        for (uint32_t k = 0; k < kSpiralChunks; ++k)
-            tab[kSpiralChunks * 64 + k] = rings_done(64u * (k + 1));
-        if (hipMalloc((void **)&e->spiral, tab.size() * 4) != hipSuccess ||
-            hipMemcpy(e->spiral, tab.data(), tab.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
-            stepth_engine_destroy(e);
-            return STEPTH_ERR_HIP;
-        }
-    }
     *out = e;
     return STEPTH_OK;
 }
@@ -283,7 +309,7 @@ void stepth_engine_destroy(stepth_engine *e)
         return;
     (void)hipSetDevice(e->device);
     (void)hipStreamSynchronize(e->stream);
-    for (DevBuf *b : {&e->T, &e->BB, &e->stage_main, &e->stage_add, &e->stage_out,
+    for (DevBuf *b : {&e->T, &e->BB, &e->spiral, &e->stage_main, &e->stage_add, &e->stage_out,
                       &e->stage_groups, &e->queries, &e->raw, &e->aux32, &e->aux_pos,
                       &e->aux_found, &e->sad_left, &e->sad_right})
         release(*b);
@@ -291,8 +317,6 @@ void stepth_engine_destroy(stepth_engine *e)
         (void)hipFree(e->words);
     if (e->stats)
         (void)hipFree(e->stats);
-    if (e->spiral)
-        (void)hipFree(e->spiral);
     for (auto &ev : e->events) {
         (void)hipEventDestroy(ev.first);
         (void)hipEventDestroy(ev.second);

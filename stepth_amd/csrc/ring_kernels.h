@@ -198,8 +198,9 @@ struct RingArgs {
     uint8_t *found;    // optional: Some/None
     uint32_t *max_word; // atomicMax of raw, depth_image.rs:124
     unsigned long long *stats; // optional [ring0_hits, probes]
-    const uint32_t *spiral;      // kSpiralChunks*64 block-spiral slots (host-built)
-    const uint32_t *spiral_done; // kSpiralChunks: complete block-rings after chunk k
+    const uint32_t *spiral;      // block-spiral slots, spiral_chunks*64 entries (host-built)
+    const uint32_t *spiral_done; // per chunk k: complete block-rings after slots [0,64(k+1))
+    uint32_t pos_bits;           // key layout, see scan_key
 };
 
 constexpr uint32_t kNoKey = 0xFFFFFFFFu;
@@ -223,8 +224,10 @@ __device__ __forceinline__ uint32_t wave_min_dpp(uint32_t v)
 // Order-preserving key of a cell in the reference's scan (helpers.rs:26-31): ring
 // s = max(|dx|,|dy|) first, then the side (row y+s, row y-s, column x+s, column x-s), then
 // the position along that side (ascending).  A corner belongs to the row that reaches it
-// first.  Bits: s [19:11], side [10:9], position [8:0] (position <= 2*254).
-__device__ __forceinline__ uint32_t scan_key(int dx, int dy, uint32_t &ring)
+// first.  Layout: position in bits [pb-1:0] (<= 2 (s_cap-1)), side in [pb+1:pb], ring above;
+// pb is chosen on the host from the largest ring the launch can reach (pb = 9 for the
+// reference's max = 255).
+__device__ __forceinline__ uint32_t scan_key(int dx, int dy, uint32_t pb, uint32_t &ring)
 {
     const int ndx = -dx, ndy = -dy;
     const int s = max(max(dx, ndx), max(dy, ndy));
@@ -232,20 +235,23 @@ __device__ __forceinline__ uint32_t scan_key(int dx, int dy, uint32_t &ring)
     const uint32_t side = top ? 0u : bot ? 1u : dx == s ? 2u : 3u;
     const int pos = ((top || bot) ? dx : dy) + s;
     ring = (uint32_t)s;
-    return ((uint32_t)s << 11) | (side << 9) | (uint32_t)pos;
+    return ((((uint32_t)s << 2) | side) << pb) | (uint32_t)pos;
 }
 
-__device__ __forceinline__ void key_to_offset(uint32_t key, int &dx, int &dy)
+__device__ __forceinline__ void key_to_offset(uint32_t key, uint32_t pb, int &dx, int &dy)
 {
-    const int s = (int)(key >> 11), side = (int)((key >> 9) & 3u), off = (int)(key & 511u) - s;
+    const int s = (int)(key >> (pb + 2u)), side = (int)((key >> pb) & 3u);
+    const int off = (int)(key & ((1u << pb) - 1u)) - s;
     dx = side < 2 ? off : side == 2 ? s : -s;
     dy = side == 0 ? s : side == 1 ? -s : off;
 }
 
 // Block spiral: slot u -> block offset (bi, bj) from the centre block.  Block-ring m holds
 // slots [(2m-1)^2, (2m+1)^2), walked as a pinwheel of four sides of 2m blocks; slot 0 is the
-// centre block.  The first kSpiralSlots slots come from a host-built table staged in LDS
-// (entry = (bi & 0xffff) | (bj << 16)); anything beyond (max_steps > 264) is computed.
+// centre block.  The table is query independent and host-built (entry = (bi & 0xffff) |
+// (bj << 16), then one word per 64-slot chunk: complete block-rings after that chunk); its
+// first kSpiralChunks chunks -- enough for max_steps <= 258, the reference uses 255 -- are
+// staged in LDS, later chunks are read from global memory.
 constexpr uint32_t kSpiralRings = 33;                                   // block-rings 0..33
 constexpr uint32_t kSpiralSlots = (2 * kSpiralRings + 1) * (2 * kSpiralRings + 1); // 4489
 constexpr uint32_t kSpiralChunks = (kSpiralSlots + 63) / 64;            // 71
@@ -274,7 +280,7 @@ __global__ __launch_bounds__(256) void ring_match_kernel(RingArgs a)
     __shared__ uint32_t s_done[kSpiralChunks];
     {
         // stage the part of the spiral this launch can reach
-        const uint32_t m_cap = min((min(a.max_steps, 0x10000u) + 6u) >> 3, kSpiralRings);
+        const uint32_t m_cap = min((min(a.max_steps, 0x10000u) + 6u) >> 3, kSpiralRings + 1u);
         const uint32_t need = min((2u * m_cap + 1u) * (2u * m_cap + 1u), kSpiralChunks * 64u);
         for (uint32_t i = threadIdx.x; i < need; i += blockDim.x)
             s_spiral[i] = a.spiral[i];
@@ -326,6 +332,7 @@ __global__ __launch_bounds__(256) void ring_match_kernel(RingArgs a)
     // ---- phase B: survivors, whole wave per query ---------------------------------------
     unsigned long long pend = __ballot(pending);
     const int lx = (int)(lane & 7u), ly = (int)(lane >> 3);
+    const uint32_t ring_shift = a.pos_bits + 2u;
     while (pend) {
         const int src = __ffsll(pend) - 1;
         pend &= pend - 1;
@@ -343,14 +350,8 @@ __global__ __launch_bounds__(256) void ring_match_kernel(RingArgs a)
         uint32_t limit = s_end;  // a block whose nearest cell is at ring >= limit is useless
         for (uint32_t u0 = 0, k = 0; u0 < u_end; u0 += 64u, ++k) {
             // -- one step of block tests: 64 slots of the spiral, one lane each --
-            int bi, bj;
-            if (k < kSpiralChunks) {
-                const uint32_t e = s_spiral[u0 + lane];
-                bi = (int)(short)(e & 0xffffu);
-                bj = (int)e >> 16;
-            } else {
-                block_slot(u0 + lane, bi, bj);
-            }
+            const uint32_t e = k < kSpiralChunks ? s_spiral[u0 + lane] : a.spiral[u0 + lane];
+            const int bi = (int)(short)(e & 0xffffu), bj = (int)e >> 16;
             const int bx = cbx + bi, by = cby + bj;
             // smallest ring index of any cell of this block: max over axes of
             // max(8b - o, o - 8b - 7, 0)
@@ -378,25 +379,24 @@ __global__ __launch_bounds__(256) void ring_match_kernel(RingArgs a)
                 const bool hit = cell_in_box(c, qlo, qhi);
                 if (__ballot(hit)) { // keys only when some cell of the block matched
                     uint32_t ring;
-                    const uint32_t key = scan_key(sbi * 8 + rx, sbj * 8 + ry, ring);
+                    const uint32_t key = scan_key(sbi * 8 + rx, sbj * 8 + ry, a.pos_bits, ring);
                     if (hit && ring < s_end)
                         mine = min(mine, key);
                 }
             }
             if (__ballot(mine != kNoKey)) {
                 best = min(best, wave_min_dpp(mine));
-                limit = min(limit, (best >> 11) + 1u);
+                limit = min(limit, (best >> ring_shift) + 1u);
             }
             // block-rings 0..m_done are complete after this step: every cell of rings
             // <= 8 m_done has been seen or excluded
-            const uint32_t m_done = k < kSpiralChunks ? s_done[k]
-                                                      : rings_done(min(u0 + 64u, u_end));
-            if (best != kNoKey && (best >> 11) <= 8u * m_done)
+            const uint32_t m_done = k < kSpiralChunks ? s_done[k] : a.spiral_done[k];
+            if (best != kNoKey && (best >> ring_shift) <= 8u * m_done)
                 break;
         }
         if ((int)lane == src && best != kNoKey) {
             fnd = true;
-            key_to_offset(best, fdx, fdy);
+            key_to_offset(best, a.pos_bits, fdx, fdy);
         }
     }
 

@@ -141,6 +141,25 @@ def test_far_hits_and_distance_extremes(engine, oracle):
     check_batch(engine, oracle, a, [[255] * 3], [[300, 300]], 254, [1, 1, 1])  # ring 254 cut off
 
 
+def test_max_steps_beyond_the_reference_255(engine, oracle):
+    """`max` is a parameter of helpers::distance_dot_array (helpers.rs:13); beyond 258 the
+    block spiral leaves its LDS-staged part and is read from global memory"""
+    rng = np.random.default_rng(5)
+    a = np.zeros((520, 640, 3), np.uint8)
+    a[500, 600] = 200   # ring 590 from (10, 10)
+    a[30, 450] = 100    # ring 440
+    a[400, 20] = 50     # ring 390
+    q = [[10, 10]] * 3 + [[320, 260]] * 3
+    what = [[200] * 3, [100] * 3, [50] * 3] * 2
+    for ms in (700, 600, 441, 440, 391, 300):
+        f, d, p = check_batch(engine, oracle, a, what, q, ms, [1, 1, 1])
+    f, d, p = check_batch(engine, oracle, a, what, q, 700, [1, 1, 1])
+    assert f.tolist() == [1] * 6 and d[0] == int(np.hypot(590, 490))
+    noise = rng.integers(0, 256, (300, 300, 3), dtype=np.uint8)
+    what = rng.integers(0, 256, (300, 3), dtype=np.uint8)
+    check_batch(engine, oracle, noise, what, rng.integers(0, 300, (300, 2)), 1000, [3, 3, 3])
+
+
 # ---- the whole path (src/depth_image.rs:96-132, no Gaussian tail) ------------------------
 
 def run_both(engine, oracle, main, add, prec, **kw):
