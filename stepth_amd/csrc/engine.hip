@@ -42,9 +42,9 @@ struct stepth_engine {
 
     DevBuf T, BB;          // packed additional image: tiled cells, block bounds
     DevBuf stage_main, stage_add, stage_out, stage_groups;
-    DevBuf queries, raw, aux32, aux_pos, aux_found;
+    DevBuf queries, raw, aux32, aux_pos, aux_found, pending, pending_rec;
     DevBuf sad_left, sad_right;
-    uint32_t *words = nullptr; // [0] max, [1] scratch max (host-visible copy target), [2..3] pad
+    uint32_t *words = nullptr; // [0] max, [1] host max staged for normalise_rows, [2] pending count, [3] next pending run
     unsigned long long *stats = nullptr; // [ring0_hits, probes]
     DevBuf spiral;                       // block-spiral table + per-chunk complete rings
     uint32_t spiral_chunks = 0;
@@ -178,6 +178,8 @@ int pack_additional(stepth_engine *e, const uint8_t *d_add, size_t stride, uint3
     bw = (wa + 7u) / 8u;
     bh = (ha + 7u) / 8u;
     const size_t nblk = (size_t)bw * bh;
+    if (nblk * 64 > 0x3FFFFFFFull) // kernels index cells with 32-bit byte offsets
+        return fail(e, STEPTH_ERR_BAD_ARG, "additional image %ux%u exceeds 2^30 cells", wa, ha);
     TRY(reserve(e, e->T, nblk * 64 * 4));
     TRY(reserve(e, e->BB, nblk * 8));
     PackArgs pa{d_add, stride, wa, ha, bw, bh, (uint32_t *)e->T.p, (uint2 *)e->BB.p};
@@ -235,20 +237,42 @@ int launch_ring(stepth_engine *e, RingArgs &ra, int qmode)
     }
     ra.spiral = (const uint32_t *)e->spiral.p;
     ra.spiral_done = ra.spiral + (size_t)e->spiral_chunks * 64;
+    TRY(reserve(e, e->pending, (size_t)ra.n * 4));
+    ra.pending = (uint32_t *)e->pending.p;
+    TRY(reserve(e, e->pending_rec, (size_t)ra.n * sizeof(Query)));
+    ra.pending_rec = (Query *)e->pending_rec.p;
+    ra.pending_count = e->words + 2;
+    ra.pending_next = e->words + 3;
+    ra.stats = e->stats_enabled ? e->stats : nullptr;
+    // search waves pull runs of queries from a counter, so any grid works; 8 workgroups of 4
+    // waves per CU is the most that can be resident
+    const uint32_t search_blocks = std::min<uint32_t>(2048u, (ra.n + 63u) / 64u);
+    // block-rings a search can reach; the LDS-staged spiral covers kSpiralRings of them
+    const bool far_search =
+        ((std::min(ra.max_steps, std::max(ra.wa, ra.ha)) + 6u) >> 3) > kSpiralRings;
     KernelTimer t(e);
+#define STEPTH_LAUNCH_PAIR(Q, S)                                                               \
+    do {                                                                                      \
+        hipLaunchKernelGGL((ring0_kernel<Q, S>), dim3(blocks), dim3(256), 0, e->stream, ra);  \
+        if (far_search)                                                                       \
+            hipLaunchKernelGGL((ring_search_kernel<S, true>), dim3(search_blocks), dim3(256),  \
+                               0, e->stream, ra);                                             \
+        else                                                                                  \
+            hipLaunchKernelGGL((ring_search_kernel<S, false>), dim3(search_blocks), dim3(256), \
+                               0, e->stream, ra);                                             \
+    } while (0)
     if (e->stats_enabled) {
-        ra.stats = e->stats;
         if (qmode == 0)
-            hipLaunchKernelGGL((ring_match_kernel<0, true>), dim3(blocks), dim3(256), 0, e->stream, ra);
+            STEPTH_LAUNCH_PAIR(0, true);
         else
-            hipLaunchKernelGGL((ring_match_kernel<1, true>), dim3(blocks), dim3(256), 0, e->stream, ra);
+            STEPTH_LAUNCH_PAIR(1, true);
     } else {
-        ra.stats = nullptr;
         if (qmode == 0)
-            hipLaunchKernelGGL((ring_match_kernel<0, false>), dim3(blocks), dim3(256), 0, e->stream, ra);
+            STEPTH_LAUNCH_PAIR(0, false);
         else
-            hipLaunchKernelGGL((ring_match_kernel<1, false>), dim3(blocks), dim3(256), 0, e->stream, ra);
+            STEPTH_LAUNCH_PAIR(1, false);
     }
+#undef STEPTH_LAUNCH_PAIR
     HIP_TRY(e, hipGetLastError());
     return STEPTH_OK;
 }
@@ -311,7 +335,7 @@ void stepth_engine_destroy(stepth_engine *e)
     (void)hipStreamSynchronize(e->stream);
     for (DevBuf *b : {&e->T, &e->BB, &e->spiral, &e->stage_main, &e->stage_add, &e->stage_out,
                       &e->stage_groups, &e->queries, &e->raw, &e->aux32, &e->aux_pos,
-                      &e->aux_found, &e->sad_left, &e->sad_right})
+                      &e->aux_found, &e->pending, &e->pending_rec, &e->sad_left, &e->sad_right})
         release(*b);
     if (e->words)
         (void)hipFree(e->words);
@@ -402,7 +426,7 @@ int stepth_depth_from_additional(stepth_engine *e, const stepth_image *main_im,
         d_out = static_cast<uint8_t *>(e->stage_out.p);
     }
 
-    hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(64), 0, e->stream, e->words, 2);
+    hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(64), 0, e->stream, e->words, 4);
 
     if (p.mode == STEPTH_MODE_SAD_WINDOW) {
         if (groups)
@@ -695,7 +719,7 @@ int stepth_distance_dot_array_batch(stepth_engine *e, const stepth_image *array,
     TRY(reserve(e, e->aux_found, std::max<size_t>(n, 4)));
     HIP_TRY(e, hipMemcpyAsync(e->queries.p, qs.data(), n * sizeof(Query), hipMemcpyHostToDevice,
                               e->stream));
-    hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(64), 0, e->stream, e->words, 2);
+    hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(64), 0, e->stream, e->words, 4);
     RingArgs ra{};
     ra.T = (const uint32_t *)e->T.p;
     ra.BB = (const uint2 *)e->BB.p;

@@ -156,24 +156,33 @@ __global__ __launch_bounds__(256) void prep_list_kernel(PrepArgs a)
 }
 
 // ---------------------------------------------------------------------------------------
-// ring_match: PASS 1 (src/depth_image.rs:112-123) with helpers::distance_dot_array inlined.
+// PASS 1 (src/depth_image.rs:112-123) with helpers::distance_dot_array inlined: two kernels.
 //
 // The reference walks rings s = 0,1,2,.. around `middle` and, inside a ring, row y+s, row
 // y-s, column x+s, column x-s, each ascending (helpers.rs:26-31), and returns the first cell
-// inside the colour box.  Give every cell the key (s << 12) | position-in-that-scan: the
-// answer is the matching cell with the smallest key, so cells may be examined in ANY order
-// and most of them need not be examined at all:
+// inside the colour box.  Give every cell the key ring|side|position of that scan: the answer
+// is the matching cell with the smallest key, so cells may be examined in ANY order and most
+// of them need not be examined at all.
 //
-//   * phase A: every lane tests its own query's centre cell (ring 0) -- on natural images
-//     a large share of the queries ends here;
-//   * phase B serves the survivors one at a time with the whole wave.  The 8x8 blocks around
-//     the centre block are visited in square block-rings (64 blocks per step, one lane
-//     each); a block whose channel bounds BB do not intersect the colour box cannot hold a
-//     match and is dropped after one 8-byte read -- 1/64 of the reference's probes.  Every
-//     surviving block costs one step: 64 lanes read its 64 cells (256 contiguous bytes),
-//     test them and keep the smallest key.
-//   * all cells of rings s <= 8 M lie in block-rings <= M, so once block-rings 0..M are
-//     done and the best key's ring is <= 8 M, no unvisited cell can beat it: stop.
+//   ring0_kernel   dense, one lane per query: tests the centre cell (ring 0) -- on natural
+//                  images a large share of the queries ends here -- writes the result 0 for
+//                  every query and compacts the survivors into `pending` (one wave-aggregated
+//                  atomic per wave).
+//   ring_search_kernel   persistent waves, ONE query per wave at a time, queries dealt
+//                  round-robin (wave w takes pending[w], pending[w+NW], ..): the work per
+//                  query is wildly uneven (0.2 .. 30 steps), interleaving gives every wave
+//                  the same mix and keeps all concurrently running waves inside one narrow
+//                  band of the image (L2 locality).  The 8x8 blocks around the centre block
+//                  are visited along a square spiral, 64 blocks per step (one lane each,
+//                  offsets from an LDS-staged table, bounds prefetched one step ahead); a
+//                  block whose channel bounds BB miss the colour box cannot hold a match and
+//                  is dropped after one 8-byte read -- 1/64 of the reference's probes.  Every
+//                  surviving block costs one step: 64 lanes read its 64 cells (256 contiguous
+//                  bytes, two blocks in flight), test them and, only if some cell matched,
+//                  compute keys and keep the smallest.
+//                  All cells of rings s <= 8 M lie in block-rings <= M, so once block-rings
+//                  0..M are done and the best key's ring is <= 8 M no unvisited cell can beat
+//                  it: stop.  Blocks whose nearest cell lies beyond the best ring are skipped.
 //
 // A ring search ends at the first ring with no in-bounds cell (helpers.rs:49-51): ring
 // max(cx, Wa-1-cx, cy, Ha-1-cy)+1 for an in-bounds centre, and immediately (None) for a
@@ -201,9 +210,23 @@ struct RingArgs {
     const uint32_t *spiral;      // block-spiral slots, spiral_chunks*64 entries (host-built)
     const uint32_t *spiral_done; // per chunk k: complete block-rings after slots [0,64(k+1))
     uint32_t pos_bits;           // key layout, see scan_key
+    uint32_t *pending;           // n: ids of the queries that missed at ring 0 (compacted by
+                                 // ring0_kernel), and their records {cx,cy,lo,hi}
+    Query *pending_rec;
+    uint32_t *pending_count;     // 1 word, zeroed before ring0_kernel
+    uint32_t *pending_next;      // 1 word, zeroed: next run of `pending` to hand out
 };
 
 constexpr uint32_t kNoKey = 0xFFFFFFFFu;
+#ifndef STEPTH_RUN
+#define STEPTH_RUN 16
+#endif
+// <= 80 SGPRs keeps 8 workgroups of 256 threads resident per CU (MI355X_MICROARCH.md,
+// "Residency"); the kernel wants ~100 without the cap
+#ifndef STEPTH_SEARCH_ATTR
+#define STEPTH_SEARCH_ATTR __attribute__((amdgpu_num_sgpr(80)))
+#endif
+constexpr uint32_t kRun = STEPTH_RUN; // consecutive pending queries a wave takes at a time
 
 __device__ __forceinline__ uint32_t bcast(uint32_t v, int src_lane)
 {
@@ -273,12 +296,84 @@ STEPTH_HD void block_slot(uint32_t u, int &i, int &j)
 // (2m+1)^2 <= done
 STEPTH_HD uint32_t rings_done(uint32_t done) { return (isqrt_floor(done) - 1u) >> 1; }
 
-template <int QMODE, bool STATS>
-__global__ __launch_bounds__(256) void ring_match_kernel(RingArgs a)
+template <int QMODE>
+__device__ __forceinline__ void load_query(const RingArgs &a, uint32_t q, uint32_t &cx,
+                                           uint32_t &cy, uint32_t &lo, uint32_t &hi)
 {
-    __shared__ uint32_t s_spiral[kSpiralChunks * 64];
-    __shared__ uint32_t s_done[kSpiralChunks];
-    {
+    if constexpr (QMODE == 0) {
+        const uint32_t x = q % a.w, y = a.row0 + q / a.w;
+        const uint8_t *p = a.main_px + (size_t)y * a.mstride + (size_t)x * a.mch;
+        const uint8_t v[3] = {p[0], p[1], p[2]};
+        cx = (x + 1u) >> 1; // (x + 1)/2, (y + 1)/2 for a 1x1 group, depth_image.rs:114-117
+        cy = (y + 1u) >> 1;
+        make_box(v, a.prec, lo, hi);
+    } else {
+        const Query qq = a.queries[q];
+        cx = qq.cx;
+        cy = qq.cy;
+        lo = qq.lo;
+        hi = qq.hi;
+    }
+}
+
+template <int QMODE, bool STATS>
+__global__ __launch_bounds__(256) void ring0_kernel(RingArgs a)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t q = blockIdx.x * 256u + threadIdx.x;
+    const bool valid = q < a.n;
+    uint32_t cx = ~0u, cy = ~0u, lo = 0, hi = 0;
+    if (valid)
+        load_query<QMODE>(a, q, cx, cy, lo, hi);
+    const bool inb = valid && cx < a.wa && cy < a.ha && a.max_steps > 0;
+    bool fnd = false, pending = false;
+    if (inb) {
+        const size_t blk = (size_t)(cy >> kBlkShift) * a.bw + (cx >> kBlkShift);
+        const uint32_t c = a.T[blk * 64u + ((cy & 7u) << 3) + (cx & 7u)];
+        fnd = cell_in_box(c, lo, hi);
+        pending = !fnd && a.max_steps > 1;
+    }
+    if (valid) { // a ring-0 hit has distance 0; None is 0 too (depth_image.rs:118-121)
+        a.raw[q] = 0;
+        if (a.raw32)
+            a.raw32[q] = 0;
+        if (a.pos) {
+            a.pos[2 * (size_t)q] = fnd ? cx : 0u;
+            a.pos[2 * (size_t)q + 1] = fnd ? cy : 0u;
+        }
+        if (a.found)
+            a.found[q] = fnd ? 1 : 0;
+    }
+    const unsigned long long pm = __ballot(pending);
+    if (pm) {
+        uint32_t base = 0;
+        if (lane == 0)
+            base = atomicAdd(a.pending_count, (uint32_t)__popcll(pm));
+        base = bcast(base, 0);
+        if (pending) {
+            const uint32_t slot = base + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull));
+            a.pending[slot] = q;
+            a.pending_rec[slot] = Query{cx, cy, lo, hi};
+        }
+    }
+    if constexpr (STATS) {
+        const unsigned long long h = __popcll(__ballot(fnd)), pr = __popcll(__ballot(inb));
+        if (lane == 0) {
+            atomicAdd(&a.stats[0], h);
+            atomicAdd(&a.stats[1], pr);
+        }
+    }
+}
+
+// FAR = false: max_steps <= 258 (the reference uses 255), the spiral comes from LDS only;
+// FAR = true: longer searches read the table from global memory only.  (One kernel choosing
+// between an LDS and a global pointer at run time is compiled to slow flat loads.)
+template <bool STATS, bool FAR>
+__global__ __launch_bounds__(256) STEPTH_SEARCH_ATTR void ring_search_kernel(RingArgs a)
+{
+    __shared__ uint32_t s_spiral[FAR ? 64 : kSpiralChunks * 64];
+    __shared__ uint32_t s_done[FAR ? 1 : kSpiralChunks];
+    if constexpr (!FAR) {
         // stage the part of the spiral this launch can reach
         const uint32_t m_cap = min((min(a.max_steps, 0x10000u) + 6u) >> 3, kSpiralRings + 1u);
         const uint32_t need = min((2u * m_cap + 1u) * (2u * m_cap + 1u), kSpiralChunks * 64u);
@@ -289,141 +384,170 @@ __global__ __launch_bounds__(256) void ring_match_kernel(RingArgs a)
         __syncthreads();
     }
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);
-    const uint32_t q = wave * 64u + lane;
-    const bool valid = q < a.n;
-
-    uint32_t cx = ~0u, cy = ~0u, lo = 0, hi = 0;
-    if (valid) {
-        if constexpr (QMODE == 0) {
-            const uint32_t x = q % a.w, y = a.row0 + q / a.w;
-            const uint8_t *p = a.main_px + (size_t)y * a.mstride + (size_t)x * a.mch;
-            const uint8_t v[3] = {p[0], p[1], p[2]};
-            cx = (x + 1u) >> 1; // (x + 1)/2, (y + 1)/2 for a 1x1 group
-            cy = (y + 1u) >> 1;
-            make_box(v, a.prec, lo, hi);
-        } else {
-            const Query qq = a.queries[q];
-            cx = qq.cx;
-            cy = qq.cy;
-            lo = qq.lo;
-            hi = qq.hi;
-        }
-    }
-
-    // ---- phase A: ring 0, one lane per query ------------------------------------------
-    const bool inb = valid && cx < a.wa && cy < a.ha && a.max_steps > 0;
-    bool fnd = false;
-    int fdx = 0, fdy = 0;
-    bool pending = false;
-    if (inb) {
-        const size_t blk = (size_t)(cy >> kBlkShift) * a.bw + (cx >> kBlkShift);
-        const uint32_t c = a.T[blk * 64u + ((cy & 7u) << 3) + (cx & 7u)];
-        if (cell_in_box(c, lo, hi))
-            fnd = true;
-        else
-            pending = a.max_steps > 1;
-    }
-    unsigned long long n_probe = 0;
-    if constexpr (STATS)
-        n_probe = __popcll(__ballot(inb));
-    const unsigned long long ring0 = STATS ? __popcll(__ballot(fnd)) : 0;
-
-    // ---- phase B: survivors, whole wave per query ---------------------------------------
-    unsigned long long pend = __ballot(pending);
     const int lx = (int)(lane & 7u), ly = (int)(lane >> 3);
     const uint32_t ring_shift = a.pos_bits + 2u;
-    while (pend) {
-        const int src = __ffsll(pend) - 1;
-        pend &= pend - 1;
-        const uint32_t qx = bcast(cx, src), qy = bcast(cy, src);
-        const uint32_t qlo = bcast(lo, src), qhi = bcast(hi, src);
+    const uint32_t count = *a.pending_count;
+    unsigned long long n_probe = 0;
+    uint32_t wave_max = 0;
+
+    // Work is handed out dynamically in runs of kRun consecutive pending entries (one atomic
+    // per run): the cost of a query varies by two orders of magnitude, and a static split
+    // would also depend on how many workgroups are resident at once.
+#ifdef STEPTH_STATIC
+    for (uint32_t run0 = (blockIdx.x * 4u + (threadIdx.x >> 6)) * kRun; run0 < count;
+         run0 += gridDim.x * 4u * kRun) {
+#else
+    for (;;) {
+        uint32_t run0 = 0;
+        if (lane == 0)
+            run0 = atomicAdd(a.pending_next, kRun);
+        run0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)run0);
+        if (run0 >= count)
+            break;
+#endif
+        const uint32_t run_len = min(kRun, count - run0);
+        // one coalesced read brings the whole run: lane i holds query run0 + i
+        Query rec = Query{0u, 0u, 0u, 0u};
+        uint32_t rq = 0;
+        if (lane < run_len) {
+            rec = a.pending_rec[run0 + lane];
+            rq = a.pending[run0 + lane];
+        }
+    for (uint32_t r = 0; r < run_len; ++r) {
+        const uint32_t q = bcast(rq, (int)r);
+        const uint32_t qx = bcast(rec.cx, (int)r), qy = bcast(rec.cy, (int)r);
+        const uint32_t qlo = bcast(rec.lo, (int)r), qhi = bcast(rec.hi, (int)r);
+
         const uint32_t smax = max(max(qx, a.wa - 1u - qx), max(qy, a.ha - 1u - qy));
         const uint32_t s_end = min(a.max_steps, smax + 1u); // rings 0..s_end-1 are searched
         const int cbx = (int)(qx >> kBlkShift), cby = (int)(qy >> kBlkShift);
         const int nox = -(int)(qx & 7u), noy = -(int)(qy & 7u);
-        const uint32_t m_end = (s_end + 6u) >> 3;             // last block-ring with ring < s_end
+        const uint32_t m_end = (s_end + 6u) >> 3; // last block-ring holding a ring < s_end
         const uint32_t u_end = (2u * m_end + 1u) * (2u * m_end + 1u);
-        const int rx = cbx * 8 - (int)qx + lx, ry = cby * 8 - (int)qy + ly; // lane's cell offset
-                                                                            // inside block (0,0)
-        uint32_t best = kNoKey;  // wave-uniform best key so far
-        uint32_t limit = s_end;  // a block whose nearest cell is at ring >= limit is useless
-        for (uint32_t u0 = 0, k = 0; u0 < u_end; u0 += 64u, ++k) {
-            // -- one step of block tests: 64 slots of the spiral, one lane each --
-            const uint32_t e = k < kSpiralChunks ? s_spiral[u0 + lane] : a.spiral[u0 + lane];
-            const int bi = (int)(short)(e & 0xffffu), bj = (int)e >> 16;
+        const int rx = cbx * 8 - (int)qx + lx, ry = cby * 8 - (int)qy + ly; // lane's cell in
+                                                                            // block (0,0)
+        uint32_t best = kNoKey; // wave-uniform best key so far
+        uint32_t limit = s_end; // a block whose nearest cell is at ring >= limit is useless
+
+        // one step of block tests = 64 slots of the spiral, one lane each; the bounds of the
+        // NEXT step are fetched while this step's surviving blocks are probed
+        auto fetch = [&](uint32_t u0, uint32_t k, int &bi, int &bj, uint32_t &dmin, bool &ok,
+                         uint2 &bb) {
+            uint32_t e;
+            if constexpr (FAR)
+                e = a.spiral[u0 + lane];
+            else
+                e = s_spiral[u0 + lane];
+            bi = (int)(short)(e & 0xffffu);
+            bj = (int)e >> 16;
             const int bx = cbx + bi, by = cby + bj;
-            // smallest ring index of any cell of this block: max over axes of
-            // max(8b - o, o - 8b - 7, 0)
+            // smallest ring of any cell of the block: max over axes of max(8b-o, o-8b-7, 0)
             const int ax = (bi << 3) + nox, ay = (bj << 3) + noy;
-            const int dmin = max(max(max(ax, -7 - ax), max(ay, -7 - ay)), 0);
-            bool cand = u0 + lane < u_end && (uint32_t)bx < a.bw && (uint32_t)by < a.bh &&
-                        (uint32_t)dmin < limit;
-            if (cand) {
-                const uint2 bb = a.BB[(uint32_t)by * a.bw + (uint32_t)bx];
-                // box [lo,hi] meets [bmin,bmax] on every channel
-                cand = (((bb.x - qlo) & (qhi - bb.y)) | ~kGuard) == 0xFFFFFFFFu;
+            dmin = (uint32_t)max(max(max(ax, -7 - ax), max(ay, -7 - ay)), 0);
+            ok = u0 + lane < u_end && (uint32_t)bx < a.bw && (uint32_t)by < a.bh && dmin < limit;
+            bb = make_uint2(0u, 0u);
+            if (ok)
+                bb = a.BB[(uint32_t)by * a.bw + (uint32_t)bx];
+        };
+        auto probe = [&](int sbi, int sbj, uint32_t c, uint32_t &mine) {
+            const bool hit = cell_in_box(c, qlo, qhi);
+            if (__ballot(hit)) { // keys only when some cell of the block matched
+                uint32_t ring;
+                const uint32_t key = scan_key(sbi * 8 + rx, sbj * 8 + ry, a.pos_bits, ring);
+                if (hit && ring < s_end)
+                    mine = min(mine, key);
             }
+        };
+
+        int bi, bj, nbi = 0, nbj = 0;
+        uint32_t dmin, ndmin = 0;
+        bool ok, nok = false;
+        uint2 bb, nbb = make_uint2(0u, 0u);
+        fetch(0u, 0u, bi, bj, dmin, ok, bb);
+        for (uint32_t u0 = 0, k = 0; u0 < u_end; u0 += 64u, ++k) {
+            // prefetch from the second step on: a search that outlives the first 64 blocks
+            // (rings <= 24) usually runs for several more
+            const bool ahead = k >= 1u && u0 + 64u < u_end;
+            if (ahead)
+                fetch(u0 + 64u, k + 1u, nbi, nbj, ndmin, nok, nbb);
+            // box [lo,hi] meets [bmin,bmax] on every channel (bb = 0 never does)
+            const bool cand = ok && dmin < limit &&
+                              (((bb.x - qlo) & (qhi - bb.y)) | ~kGuard) == 0xFFFFFFFFu;
             unsigned long long pm = __ballot(cand);
             if constexpr (STATS)
-                n_probe += __popcll(pm) * 64ull + 64ull;
+                n_probe += 64ull;
 
-            // -- one step per surviving block: its 64 cells (256 contiguous bytes) --
-            uint32_t mine = kNoKey;
-            while (pm) {
-                const int b = __ffsll(pm) - 1;
+            while (pm) { // surviving blocks, two in flight
+                const int b0 = __ffsll(pm) - 1;
                 pm &= pm - 1;
-                const int sbi = (int)bcast((uint32_t)bi, b), sbj = (int)bcast((uint32_t)bj, b);
-                const uint32_t sblk = (uint32_t)(cby + sbj) * a.bw + (uint32_t)(cbx + sbi);
-                const uint32_t c = a.T[(size_t)sblk * 64u + lane];
-                const bool hit = cell_in_box(c, qlo, qhi);
-                if (__ballot(hit)) { // keys only when some cell of the block matched
-                    uint32_t ring;
-                    const uint32_t key = scan_key(sbi * 8 + rx, sbj * 8 + ry, a.pos_bits, ring);
-                    if (hit && ring < s_end)
-                        mine = min(mine, key);
+                const bool two = pm != 0;
+                const int b1 = two ? __ffsll(pm) - 1 : b0;
+                pm &= pm - 1; // no-op when pm == 0
+                const int i0 = (int)bcast((uint32_t)bi, b0), j0 = (int)bcast((uint32_t)bj, b0);
+                const int i1 = (int)bcast((uint32_t)bi, b1), j1 = (int)bcast((uint32_t)bj, b1);
+                const uint32_t blk0 = (uint32_t)(cby + j0) * a.bw + (uint32_t)(cbx + i0);
+                const uint32_t blk1 = (uint32_t)(cby + j1) * a.bw + (uint32_t)(cbx + i1);
+                const uint32_t c0 = a.T[blk0 * 64u + lane];
+                const uint32_t c1 = a.T[blk1 * 64u + lane];
+                uint32_t mine = kNoKey;
+                probe(i0, j0, c0, mine);
+                if (two)
+                    probe(i1, j1, c1, mine);
+                if constexpr (STATS)
+                    n_probe += two ? 128ull : 64ull;
+                if (__ballot(mine != kNoKey)) {
+                    // a match: everything farther than its ring is now useless, including
+                    // the rest of this step's survivors
+                    best = min(best, wave_min_dpp(mine));
+                    limit = min(limit, (best >> ring_shift) + 1u);
+                    pm &= __ballot(dmin < limit);
                 }
-            }
-            if (__ballot(mine != kNoKey)) {
-                best = min(best, wave_min_dpp(mine));
-                limit = min(limit, (best >> ring_shift) + 1u);
             }
             // block-rings 0..m_done are complete after this step: every cell of rings
             // <= 8 m_done has been seen or excluded
-            const uint32_t m_done = k < kSpiralChunks ? s_done[k] : a.spiral_done[k];
+            uint32_t m_done;
+            if constexpr (FAR)
+                m_done = a.spiral_done[k];
+            else
+                m_done = s_done[k];
             if (best != kNoKey && (best >> ring_shift) <= 8u * m_done)
                 break;
+            if (ahead) {
+                bi = nbi;
+                bj = nbj;
+                dmin = ndmin;
+                ok = nok;
+                bb = nbb;
+            } else if (u0 + 64u < u_end) {
+                fetch(u0 + 64u, k + 1u, bi, bj, dmin, ok, bb);
+            }
         }
-        if ((int)lane == src && best != kNoKey) {
-            fnd = true;
-            key_to_offset(best, a.pos_bits, fdx, fdy);
-        }
-    }
 
-    // ---- epilogue: distance (helpers.rs:3-7), u8 wrap (depth_image.rs:121), max (:124) ----
-    uint32_t d = 0;
-    if (fnd)
-        d = isqrt_floor((uint32_t)(fdx * fdx + fdy * fdy));
-    const uint32_t d8 = d & 0xffu;
-    if (valid) {
-        a.raw[q] = (uint8_t)d8;
-        if (a.raw32)
-            a.raw32[q] = d;
-        if (a.pos) {
-            a.pos[2 * (size_t)q] = fnd ? (uint32_t)((int)cx + fdx) : 0u;
-            a.pos[2 * (size_t)q + 1] = fnd ? (uint32_t)((int)cy + fdy) : 0u;
+        // distance (helpers.rs:3-7), u8 wrap (depth_image.rs:121); None stays 0 from ring0
+        if (best != kNoKey) {
+            int fdx, fdy;
+            key_to_offset(best, a.pos_bits, fdx, fdy);
+            const uint32_t d = isqrt_floor((uint32_t)(fdx * fdx + fdy * fdy));
+            wave_max = max(wave_max, d & 0xffu);
+            if (lane == 0) {
+                a.raw[q] = (uint8_t)(d & 0xffu);
+                if (a.raw32)
+                    a.raw32[q] = d;
+                if (a.pos) {
+                    a.pos[2 * (size_t)q] = (uint32_t)((int)qx + fdx);
+                    a.pos[2 * (size_t)q + 1] = (uint32_t)((int)qy + fdy);
+                }
+                if (a.found)
+                    a.found[q] = 1;
+            }
         }
-        if (a.found)
-            a.found[q] = fnd ? 1 : 0;
     }
-    const uint32_t m = wave_max_u32(valid ? d8 : 0u);
-    if (lane == 0) {
-        if (m)
-            atomicMax(a.max_word, m);
-        if constexpr (STATS) {
-            atomicAdd(&a.stats[0], ring0);
+    }
+    if (lane == 0) { // global max, depth_image.rs:124
+        if (wave_max)
+            atomicMax(a.max_word, wave_max);
+        if constexpr (STATS)
             atomicAdd(&a.stats[1], n_probe);
-        }
     }
 }
 
