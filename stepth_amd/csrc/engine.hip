@@ -34,13 +34,17 @@ struct DevBuf {
 
 } // namespace
 
+// words: [0] max, [1] host max staged for normalise_rows, [2] pending count, then from word 32
+// on the kParts run counters of ring_search_kernel
+constexpr size_t kWordsBytes = (32 + kParts * kPartStride) * 4;
+
 struct stepth_engine {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     std::string err;
 
-    DevBuf T, BB;          // packed additional image: tiled cells, block bounds
+    DevBuf T, BB, SB;      // packed additional image: tiled cells, block / superblock bounds
     DevBuf stage_main, stage_add, stage_out, stage_groups;
     DevBuf queries, raw, aux32, aux_pos, aux_found, pending, pending_rec;
     DevBuf sad_left, sad_right;
@@ -185,6 +189,10 @@ int pack_additional(stepth_engine *e, const uint8_t *d_add, size_t stride, uint3
     PackArgs pa{d_add, stride, wa, ha, bw, bh, (uint32_t *)e->T.p, (uint2 *)e->BB.p};
     hipLaunchKernelGGL(pack_additional_kernel, dim3((uint32_t)((nblk + 3) / 4)), dim3(256), 0,
                        e->stream, pa);
+    const uint32_t sbw = (bw + 7u) / 8u, sbh = (bh + 7u) / 8u;
+    TRY(reserve(e, e->SB, (size_t)sbw * sbh * 8));
+    SuperArgs sa{(const uint2 *)e->BB.p, bw, bh, sbw, sbh, (uint2 *)e->SB.p};
+    hipLaunchKernelGGL(pack_super_kernel, dim3((sbw * sbh + 3u) / 4u), dim3(256), 0, e->stream, sa);
     HIP_TRY(e, hipGetLastError());
     return STEPTH_OK;
 }
@@ -219,7 +227,7 @@ int launch_ring(stepth_engine *e, RingArgs &ra, int qmode)
 {
     if (ra.n == 0)
         return STEPTH_OK;
-    const uint32_t blocks = (ra.n + 255u) / 256u;
+    const uint32_t blocks = (ra.n + 256u * kRing0Iters - 1u) / (256u * kRing0Iters);
     TRY(ensure_spiral(e, ra.max_steps, ra.wa, ra.ha));
     {
         // 32-bit scan keys: ring | side(2) | position; sized for the farthest reachable ring
@@ -242,7 +250,7 @@ int launch_ring(stepth_engine *e, RingArgs &ra, int qmode)
     TRY(reserve(e, e->pending_rec, (size_t)ra.n * sizeof(Query)));
     ra.pending_rec = (Query *)e->pending_rec.p;
     ra.pending_count = e->words + 2;
-    ra.pending_next = e->words + 3;
+    ra.pending_next = e->words + 32;
     ra.stats = e->stats_enabled ? e->stats : nullptr;
     // search waves pull runs of queries from a counter, so any grid works; 8 workgroups of 4
     // waves per CU is the most that can be resident
@@ -315,13 +323,13 @@ int stepth_engine_create(int device_id, stepth_engine **out)
     e->device = device_id;
     if (hipSetDevice(device_id) != hipSuccess ||
         hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking) != hipSuccess ||
-        hipMalloc((void **)&e->words, 64) != hipSuccess ||
+        hipMalloc((void **)&e->words, kWordsBytes) != hipSuccess ||
         hipMalloc((void **)&e->stats, 64) != hipSuccess) {
         stepth_engine_destroy(e);
         return STEPTH_ERR_HIP;
     }
     e->stream = e->own_stream;
-    (void)hipMemsetAsync(e->words, 0, 64, e->stream);
+    (void)hipMemsetAsync(e->words, 0, kWordsBytes, e->stream);
     (void)hipMemsetAsync(e->stats, 0, 64, e->stream);
     *out = e;
     return STEPTH_OK;
@@ -333,7 +341,7 @@ void stepth_engine_destroy(stepth_engine *e)
         return;
     (void)hipSetDevice(e->device);
     (void)hipStreamSynchronize(e->stream);
-    for (DevBuf *b : {&e->T, &e->BB, &e->spiral, &e->stage_main, &e->stage_add, &e->stage_out,
+    for (DevBuf *b : {&e->T, &e->BB, &e->SB, &e->spiral, &e->stage_main, &e->stage_add, &e->stage_out,
                       &e->stage_groups, &e->queries, &e->raw, &e->aux32, &e->aux_pos,
                       &e->aux_found, &e->pending, &e->pending_rec, &e->sad_left, &e->sad_right})
         release(*b);
@@ -426,7 +434,7 @@ int stepth_depth_from_additional(stepth_engine *e, const stepth_image *main_im,
         d_out = static_cast<uint8_t *>(e->stage_out.p);
     }
 
-    hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(64), 0, e->stream, e->words, 4);
+    HIP_TRY(e, hipMemsetAsync(e->words, 0, kWordsBytes, e->stream));
 
     if (p.mode == STEPTH_MODE_SAD_WINDOW) {
         if (groups)
@@ -485,6 +493,9 @@ int stepth_depth_from_additional(stepth_engine *e, const stepth_image *main_im,
         RingArgs ra{};
         ra.T = (const uint32_t *)e->T.p;
         ra.BB = (const uint2 *)e->BB.p;
+        ra.SB = (const uint2 *)e->SB.p;
+        ra.sbw = (bw + 7u) / 8u;
+        ra.sbh = (bh + 7u) / 8u;
         ra.wa = add_im->width;
         ra.ha = add_im->height;
         ra.bw = bw;
@@ -719,10 +730,13 @@ int stepth_distance_dot_array_batch(stepth_engine *e, const stepth_image *array,
     TRY(reserve(e, e->aux_found, std::max<size_t>(n, 4)));
     HIP_TRY(e, hipMemcpyAsync(e->queries.p, qs.data(), n * sizeof(Query), hipMemcpyHostToDevice,
                               e->stream));
-    hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(64), 0, e->stream, e->words, 4);
+    HIP_TRY(e, hipMemsetAsync(e->words, 0, kWordsBytes, e->stream));
     RingArgs ra{};
     ra.T = (const uint32_t *)e->T.p;
     ra.BB = (const uint2 *)e->BB.p;
+    ra.SB = (const uint2 *)e->SB.p;
+    ra.sbw = (bw + 7u) / 8u;
+    ra.sbh = (bh + 7u) / 8u;
     ra.wa = array->width;
     ra.ha = array->height;
     ra.bw = bw;

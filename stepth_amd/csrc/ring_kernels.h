@@ -78,6 +78,38 @@ __global__ __launch_bounds__(256) void pack_additional_kernel(PackArgs a)
         a.BB[blk] = make_uint2(pack_cell(mx[0], mx[1], mx[2]), pack_cell(mn[0], mn[1], mn[2]));
 }
 
+// Superblock bounds: one wave folds the bounds of 8x8 blocks (64x64 cells) into SB.
+struct SuperArgs {
+    const uint2 *BB;
+    uint32_t bw, bh, sbw, sbh;
+    uint2 *SB;
+};
+
+__global__ __launch_bounds__(256) void pack_super_kernel(SuperArgs a)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t sb = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (sb >= a.sbw * a.sbh)
+        return;
+    const uint32_t bx = (sb % a.sbw) * 8u + (lane & 7u), by = (sb / a.sbw) * 8u + (lane >> 3);
+    uint32_t mn[3] = {255u, 255u, 255u}, mx[3] = {0u, 0u, 0u};
+    if (bx < a.bw && by < a.bh) {
+        const uint2 bb = a.BB[(size_t)by * a.bw + bx];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            mx[c] = (bb.x >> (10 * c)) & 0xffu;
+            mn[c] = (bb.y >> (10 * c)) & 0xffu;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        mn[c] = wave_min_u32(mn[c]);
+        mx[c] = wave_max_u32(mx[c]);
+    }
+    if (lane == 0)
+        a.SB[sb] = make_uint2(pack_cell(mx[0], mx[1], mx[2]), pack_cell(mn[0], mn[1], mn[2]));
+}
+
 // ---------------------------------------------------------------------------------------
 // Queries.  One query = one disage group (src/depth_image.rs:113-121): the search centre
 // `middle` and the colour box of its value.
@@ -191,7 +223,8 @@ __global__ __launch_bounds__(256) void prep_list_kernel(PrepArgs a)
 struct RingArgs {
     const uint32_t *T;
     const uint2 *BB;
-    uint32_t wa, ha, bw, bh;
+    const uint2 *SB; // superblock (8x8 blocks) bounds, [sbh][sbw]
+    uint32_t wa, ha, bw, bh, sbw, sbh;
     // QMODE 0: one query per main pixel (uniform 1x1 tiles), read straight from the image
     const uint8_t *main_px;
     size_t mstride;
@@ -214,7 +247,7 @@ struct RingArgs {
                                  // ring0_kernel), and their records {cx,cy,lo,hi}
     Query *pending_rec;
     uint32_t *pending_count;     // 1 word, zeroed before ring0_kernel
-    uint32_t *pending_next;      // 1 word, zeroed: next run of `pending` to hand out
+    uint32_t *pending_next;      // kParts counters kPartStride words apart, zeroed: runs handed out
 };
 
 constexpr uint32_t kNoKey = 0xFFFFFFFFu;
@@ -227,6 +260,8 @@ constexpr uint32_t kNoKey = 0xFFFFFFFFu;
 #define STEPTH_SEARCH_ATTR __attribute__((amdgpu_num_sgpr(80)))
 #endif
 constexpr uint32_t kRun = STEPTH_RUN; // consecutive pending queries a wave takes at a time
+constexpr uint32_t kParts = 16;      // run counters
+constexpr uint32_t kPartStride = 32; // words between counters (128-byte lines)
 
 __device__ __forceinline__ uint32_t bcast(uint32_t v, int src_lane)
 {
@@ -316,51 +351,82 @@ __device__ __forceinline__ void load_query(const RingArgs &a, uint32_t q, uint32
     }
 }
 
+// One returning atomic on a single address costs ~11 ns chip-wide (MI355X_MICROARCH.md,
+// "dequeue"), so the compaction counter is bumped once per WORKGROUP (kRing0Iters * 256
+// queries), not once per wave.
+constexpr uint32_t kRing0Iters = 4;
+
 template <int QMODE, bool STATS>
 __global__ __launch_bounds__(256) void ring0_kernel(RingArgs a)
 {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t q = blockIdx.x * 256u + threadIdx.x;
-    const bool valid = q < a.n;
-    uint32_t cx = ~0u, cy = ~0u, lo = 0, hi = 0;
-    if (valid)
-        load_query<QMODE>(a, q, cx, cy, lo, hi);
-    const bool inb = valid && cx < a.wa && cy < a.ha && a.max_steps > 0;
-    bool fnd = false, pending = false;
-    if (inb) {
-        const size_t blk = (size_t)(cy >> kBlkShift) * a.bw + (cx >> kBlkShift);
-        const uint32_t c = a.T[blk * 64u + ((cy & 7u) << 3) + (cx & 7u)];
-        fnd = cell_in_box(c, lo, hi);
-        pending = !fnd && a.max_steps > 1;
-    }
-    if (valid) { // a ring-0 hit has distance 0; None is 0 too (depth_image.rs:118-121)
-        a.raw[q] = 0;
-        if (a.raw32)
-            a.raw32[q] = 0;
-        if (a.pos) {
-            a.pos[2 * (size_t)q] = fnd ? cx : 0u;
-            a.pos[2 * (size_t)q + 1] = fnd ? cy : 0u;
+    __shared__ uint32_t s_wave_total[4];
+    __shared__ uint32_t s_base;
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    Query rec[kRing0Iters];
+    uint32_t pend_bits = 0, n_mine = 0;
+    unsigned long long n_hit = 0, n_inb = 0;
+#pragma unroll
+    for (uint32_t it = 0; it < kRing0Iters; ++it) {
+        const uint32_t q = (blockIdx.x * kRing0Iters + it) * 256u + threadIdx.x;
+        const bool valid = q < a.n;
+        uint32_t cx = ~0u, cy = ~0u, lo = 0, hi = 0;
+        if (valid)
+            load_query<QMODE>(a, q, cx, cy, lo, hi);
+        const bool inb = valid && cx < a.wa && cy < a.ha && a.max_steps > 0;
+        bool fnd = false, pending = false;
+        if (inb) {
+            const uint32_t blk = (cy >> kBlkShift) * a.bw + (cx >> kBlkShift);
+            const uint32_t c = a.T[blk * 64u + ((cy & 7u) << 3) + (cx & 7u)];
+            fnd = cell_in_box(c, lo, hi);
+            pending = !fnd && a.max_steps > 1;
         }
-        if (a.found)
-            a.found[q] = fnd ? 1 : 0;
+        if (valid) { // a ring-0 hit has distance 0; None is 0 too (depth_image.rs:118-121)
+            a.raw[q] = 0;
+            if (a.raw32)
+                a.raw32[q] = 0;
+            if (a.pos) {
+                a.pos[2 * (size_t)q] = fnd ? cx : 0u;
+                a.pos[2 * (size_t)q + 1] = fnd ? cy : 0u;
+            }
+            if (a.found)
+                a.found[q] = fnd ? 1 : 0;
+        }
+        rec[it] = Query{cx, cy, lo, hi};
+        const unsigned long long pm = __ballot(pending);
+        if (pending)
+            pend_bits |= 1u << it;
+        n_mine += (uint32_t)__popcll(pm); // wave-uniform: pending queries of this wave
+        if constexpr (STATS) {
+            n_hit += __popcll(__ballot(fnd));
+            n_inb += __popcll(__ballot(inb));
+        }
     }
-    const unsigned long long pm = __ballot(pending);
-    if (pm) {
-        uint32_t base = 0;
-        if (lane == 0)
-            base = atomicAdd(a.pending_count, (uint32_t)__popcll(pm));
-        base = bcast(base, 0);
+    if (lane == 0)
+        s_wave_total[wv] = n_mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t tot = s_wave_total[0] + s_wave_total[1] + s_wave_total[2] + s_wave_total[3];
+        s_base = tot ? atomicAdd(a.pending_count, tot) : 0u;
+    }
+    __syncthreads();
+    uint32_t slot = s_base;
+    for (uint32_t w = 0; w < wv; ++w)
+        slot += s_wave_total[w];
+#pragma unroll
+    for (uint32_t it = 0; it < kRing0Iters; ++it) {
+        const bool pending = (pend_bits >> it) & 1u;
+        const unsigned long long pm = __ballot(pending);
         if (pending) {
-            const uint32_t slot = base + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull));
-            a.pending[slot] = q;
-            a.pending_rec[slot] = Query{cx, cy, lo, hi};
+            const uint32_t at = slot + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull));
+            a.pending[at] = (blockIdx.x * kRing0Iters + it) * 256u + threadIdx.x;
+            a.pending_rec[at] = rec[it];
         }
+        slot += (uint32_t)__popcll(pm);
     }
     if constexpr (STATS) {
-        const unsigned long long h = __popcll(__ballot(fnd)), pr = __popcll(__ballot(inb));
         if (lane == 0) {
-            atomicAdd(&a.stats[0], h);
-            atomicAdd(&a.stats[1], pr);
+            atomicAdd(&a.stats[0], n_hit);
+            atomicAdd(&a.stats[1], n_inb);
         }
     }
 }
@@ -371,16 +437,10 @@ __global__ __launch_bounds__(256) void ring0_kernel(RingArgs a)
 template <bool STATS, bool FAR>
 __global__ __launch_bounds__(256) STEPTH_SEARCH_ATTR void ring_search_kernel(RingArgs a)
 {
-    __shared__ uint32_t s_spiral[FAR ? 64 : kSpiralChunks * 64];
-    __shared__ uint32_t s_done[FAR ? 1 : kSpiralChunks];
+    __shared__ uint32_t s_spiral[64]; // first step of the block spiral (block-rings 0..3)
     if constexpr (!FAR) {
-        // stage the part of the spiral this launch can reach
-        const uint32_t m_cap = min((min(a.max_steps, 0x10000u) + 6u) >> 3, kSpiralRings + 1u);
-        const uint32_t need = min((2u * m_cap + 1u) * (2u * m_cap + 1u), kSpiralChunks * 64u);
-        for (uint32_t i = threadIdx.x; i < need; i += blockDim.x)
-            s_spiral[i] = a.spiral[i];
-        for (uint32_t i = threadIdx.x; i < kSpiralChunks; i += blockDim.x)
-            s_done[i] = a.spiral_done[i];
+        if (threadIdx.x < 64u)
+            s_spiral[threadIdx.x] = a.spiral[threadIdx.x];
         __syncthreads();
     }
     const uint32_t lane = threadIdx.x & 63u;
@@ -393,18 +453,26 @@ __global__ __launch_bounds__(256) STEPTH_SEARCH_ATTR void ring_search_kernel(Rin
     // Work is handed out dynamically in runs of kRun consecutive pending entries (one atomic
     // per run): the cost of a query varies by two orders of magnitude, and a static split
     // would also depend on how many workgroups are resident at once.
-#ifdef STEPTH_STATIC
-    for (uint32_t run0 = (blockIdx.x * 4u + (threadIdx.x >> 6)) * kRun; run0 < count;
-         run0 += gridDim.x * 4u * kRun) {
-#else
+    // Runs are dealt from kParts interleaved partitions (run r belongs to partition r % kParts),
+    // each with its own counter on its own cache line: one counter would cap the whole chip
+    // at ~88 grabs/us.  A wave starts at partition wave % kParts and moves on when one is empty.
+    const uint32_t n_runs = (count + kRun - 1u) / kRun;
+    uint32_t part = (blockIdx.x * 4u + (threadIdx.x >> 6)) % kParts, empty = 0;
     for (;;) {
-        uint32_t run0 = 0;
-        if (lane == 0)
-            run0 = atomicAdd(a.pending_next, kRun);
-        run0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)run0);
-        if (run0 >= count)
-            break;
-#endif
+        const uint32_t part_runs = (n_runs + kParts - 1u - part) / kParts; // runs r = part (mod kParts)
+        uint32_t *ctr = a.pending_next + part * kPartStride;
+        uint32_t idx = part_runs;
+        if (lane == 0 && __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < part_runs)
+            idx = atomicAdd(ctr, 1u);
+        idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)idx);
+        if (idx >= part_runs) {
+            if (++empty == kParts)
+                break;
+            part = part + 1u == kParts ? 0u : part + 1u;
+            continue;
+        }
+        empty = 0;
+        const uint32_t run0 = (idx * kParts + part) * kRun;
         const uint32_t run_len = min(kRun, count - run0);
         // one coalesced read brings the whole run: lane i holds query run0 + i
         Query rec = Query{0u, 0u, 0u, 0u};
@@ -429,55 +497,20 @@ __global__ __launch_bounds__(256) STEPTH_SEARCH_ATTR void ring_search_kernel(Rin
         uint32_t best = kNoKey; // wave-uniform best key so far
         uint32_t limit = s_end; // a block whose nearest cell is at ring >= limit is useless
 
-        // one step of block tests = 64 slots of the spiral, one lane each; the bounds of the
-        // NEXT step are fetched while this step's surviving blocks are probed
-        auto fetch = [&](uint32_t u0, uint32_t k, int &bi, int &bj, uint32_t &dmin, bool &ok,
-                         uint2 &bb) {
-            uint32_t e;
-            if constexpr (FAR)
-                e = a.spiral[u0 + lane];
-            else
-                e = s_spiral[u0 + lane];
-            bi = (int)(short)(e & 0xffffu);
-            bj = (int)e >> 16;
-            const int bx = cbx + bi, by = cby + bj;
-            // smallest ring of any cell of the block: max over axes of max(8b-o, o-8b-7, 0)
-            const int ax = (bi << 3) + nox, ay = (bj << 3) + noy;
-            dmin = (uint32_t)max(max(max(ax, -7 - ax), max(ay, -7 - ay)), 0);
-            ok = u0 + lane < u_end && (uint32_t)bx < a.bw && (uint32_t)by < a.bh && dmin < limit;
-            bb = make_uint2(0u, 0u);
-            if (ok)
-                bb = a.BB[(uint32_t)by * a.bw + (uint32_t)bx];
-        };
+        // One step of cell probes per surviving block (two blocks in flight): 64 lanes read
+        // its 64 cells, test them and, only if some cell matched, compute keys.  `bi,bj,dmin`
+        // are per lane (lane = block of the current step), `pm` the survivors.
         auto probe = [&](int sbi, int sbj, uint32_t c, uint32_t &mine) {
             const bool hit = cell_in_box(c, qlo, qhi);
-            if (__ballot(hit)) { // keys only when some cell of the block matched
+            if (__ballot(hit)) {
                 uint32_t ring;
                 const uint32_t key = scan_key(sbi * 8 + rx, sbj * 8 + ry, a.pos_bits, ring);
                 if (hit && ring < s_end)
                     mine = min(mine, key);
             }
         };
-
-        int bi, bj, nbi = 0, nbj = 0;
-        uint32_t dmin, ndmin = 0;
-        bool ok, nok = false;
-        uint2 bb, nbb = make_uint2(0u, 0u);
-        fetch(0u, 0u, bi, bj, dmin, ok, bb);
-        for (uint32_t u0 = 0, k = 0; u0 < u_end; u0 += 64u, ++k) {
-            // prefetch from the second step on: a search that outlives the first 64 blocks
-            // (rings <= 24) usually runs for several more
-            const bool ahead = k >= 1u && u0 + 64u < u_end;
-            if (ahead)
-                fetch(u0 + 64u, k + 1u, nbi, nbj, ndmin, nok, nbb);
-            // box [lo,hi] meets [bmin,bmax] on every channel (bb = 0 never does)
-            const bool cand = ok && dmin < limit &&
-                              (((bb.x - qlo) & (qhi - bb.y)) | ~kGuard) == 0xFFFFFFFFu;
-            unsigned long long pm = __ballot(cand);
-            if constexpr (STATS)
-                n_probe += 64ull;
-
-            while (pm) { // surviving blocks, two in flight
+        auto probe_blocks = [&](unsigned long long pm, int bi, int bj, uint32_t dmin) {
+            while (pm) {
                 const int b0 = __ffsll(pm) - 1;
                 pm &= pm - 1;
                 const bool two = pm != 0;
@@ -503,23 +536,110 @@ __global__ __launch_bounds__(256) STEPTH_SEARCH_ATTR void ring_search_kernel(Rin
                     pm &= __ballot(dmin < limit);
                 }
             }
-            // block-rings 0..m_done are complete after this step: every cell of rings
-            // <= 8 m_done has been seen or excluded
-            uint32_t m_done;
-            if constexpr (FAR)
-                m_done = a.spiral_done[k];
-            else
-                m_done = s_done[k];
-            if (best != kNoKey && (best >> ring_shift) <= 8u * m_done)
-                break;
-            if (ahead) {
-                bi = nbi;
-                bj = nbj;
-                dmin = ndmin;
-                ok = nok;
-                bb = nbb;
-            } else if (u0 + 64u < u_end) {
-                fetch(u0 + 64u, k + 1u, bi, bj, dmin, ok, bb);
+        };
+        // smallest ring of any cell of block (bi,bj): max over axes of max(8b-o, o-8b-7, 0)
+        auto block_dmin = [&](int bi, int bj) {
+            const int ax = (bi << 3) + nox, ay = (bj << 3) + noy;
+            return (uint32_t)max(max(max(ax, -7 - ax), max(ay, -7 - ay)), 0);
+        };
+        // box [lo,hi] meets [bmin,bmax] on every channel
+        auto bounds_meet = [&](uint2 bb) {
+            return (((bb.x - qlo) & (qhi - bb.y)) | ~kGuard) == 0xFFFFFFFFu;
+        };
+
+        if constexpr (FAR) {
+            // ---- long searches (max_steps > 258): the whole block spiral, table in global ----
+            for (uint32_t u0 = 0, k = 0; u0 < u_end; u0 += 64u, ++k) {
+                const uint32_t e = a.spiral[u0 + lane];
+                const int bi = (int)(short)(e & 0xffffu), bj = (int)e >> 16;
+                const int bx = cbx + bi, by = cby + bj;
+                const uint32_t dmin = block_dmin(bi, bj);
+                bool cand = u0 + lane < u_end && (uint32_t)bx < a.bw && (uint32_t)by < a.bh &&
+                            dmin < limit;
+                if (cand)
+                    cand = bounds_meet(a.BB[(uint32_t)by * a.bw + (uint32_t)bx]);
+                if constexpr (STATS)
+                    n_probe += 64ull;
+                probe_blocks(__ballot(cand), bi, bj, dmin);
+                // block-rings 0..m_done are complete: every cell of rings <= 8 m_done has been
+                // seen or excluded
+                if (best != kNoKey && (best >> ring_shift) <= 8u * a.spiral_done[k])
+                    break;
+            }
+        } else {
+            // ---- near: the first 64 slots of the spiral = block-rings 0..3 (rings <= 24) ----
+            {
+                const uint32_t e = s_spiral[lane];
+                const int bi = (int)(short)(e & 0xffffu), bj = (int)e >> 16;
+                const int bx = cbx + bi, by = cby + bj;
+                const uint32_t dmin = block_dmin(bi, bj);
+                bool cand = lane < u_end && (uint32_t)bx < a.bw && (uint32_t)by < a.bh &&
+                            dmin < limit;
+                if (cand)
+                    cand = bounds_meet(a.BB[(uint32_t)by * a.bw + (uint32_t)bx]);
+                if constexpr (STATS)
+                    n_probe += 64ull;
+                probe_blocks(__ballot(cand), bi, bj, dmin);
+            }
+            const bool near_done = u_end <= 64u || (best != kNoKey && (best >> ring_shift) <= 24u);
+            if (!near_done) {
+                // ---- far: survey the 64x64-cell superblocks that overlap the window of
+                // radius limit-1; only those whose bounds meet the box can hold a match.
+                // Then one step per surviving superblock (nearest first): its 64 blocks.
+                const int rad = (int)limit - 1;
+                const int sx0 = max((int)qx - rad, 0) >> 6, sy0 = max((int)qy - rad, 0) >> 6;
+                const int sx1 = min((int)qx + rad, (int)a.wa - 1) >> 6;
+                const int sy1 = min((int)qy + rad, (int)a.ha - 1) >> 6;
+                const uint32_t nsx = (uint32_t)(sx1 - sx0 + 1);
+                const uint32_t nsb = nsx * (uint32_t)(sy1 - sy0 + 1); // <= 100 for rad <= 257
+                const uint32_t recip = 65535u / nsx + 1u;            // t / nsx for t < 128
+                uint32_t skey[2];
+                int ssx[2], ssy[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const uint32_t t = lane + 64u * h;
+                    const uint32_t ty = (t * recip) >> 16, tx = t - ty * nsx;
+                    ssx[h] = sx0 + (int)tx;
+                    ssy[h] = sy0 + (int)ty;
+                    skey[h] = kNoKey;
+                    if (t < nsb) {
+                        const int ax = (ssx[h] << 6) - (int)qx, ay = (ssy[h] << 6) - (int)qy;
+                        const uint32_t dS =
+                            (uint32_t)max(max(max(ax, -63 - ax), max(ay, -63 - ay)), 0);
+                        if (dS < limit &&
+                            bounds_meet(a.SB[(uint32_t)ssy[h] * a.sbw + (uint32_t)ssx[h]]))
+                            skey[h] = (dS << 8) | t;
+                    }
+                }
+                if constexpr (STATS)
+                    n_probe += nsb > 64u ? 128ull : 64ull;
+                for (;;) {
+                    // nearest surviving superblock that can still improve the best key
+                    const uint32_t k0 = (skey[0] >> 8) < limit ? skey[0] : kNoKey;
+                    const uint32_t k1 = (skey[1] >> 8) < limit ? skey[1] : kNoKey;
+                    if (__ballot(min(k0, k1) != kNoKey) == 0)
+                        break;
+                    const uint32_t pick = wave_min_dpp(min(k0, k1));
+                    const uint32_t t = pick & 0xffu;
+                    const int owner = (int)(t & 63u);
+                    const int sx = (int)bcast((uint32_t)(t < 64u ? ssx[0] : ssx[1]), owner);
+                    const int sy = (int)bcast((uint32_t)(t < 64u ? ssy[0] : ssy[1]), owner);
+                    if (skey[0] == pick)
+                        skey[0] = kNoKey;
+                    if (skey[1] == pick)
+                        skey[1] = kNoKey;
+                    // its 64 blocks, one lane each (blocks of rings 0..3 were done above)
+                    const int bx = sx * 8 + lx, by = sy * 8 + ly;
+                    const int bi = bx - cbx, bj = by - cby;
+                    const uint32_t dmin = block_dmin(bi, bj);
+                    bool cand = (uint32_t)bx < a.bw && (uint32_t)by < a.bh && dmin < limit &&
+                                max(abs(bi), abs(bj)) > 3;
+                    if (cand)
+                        cand = bounds_meet(a.BB[(uint32_t)by * a.bw + (uint32_t)bx]);
+                    if constexpr (STATS)
+                        n_probe += 64ull;
+                    probe_blocks(__ballot(cand), bi, bj, dmin);
+                }
             }
         }
 
