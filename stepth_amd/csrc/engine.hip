@@ -46,7 +46,7 @@ struct stepth_engine {
 
     DevBuf T, BB, SB;      // packed additional image: tiled cells, block / superblock bounds
     DevBuf stage_main, stage_add, stage_out, stage_groups;
-    DevBuf queries, raw, aux32, aux_pos, aux_found, pending, pending_rec;
+    DevBuf queries, raw, aux32, aux_pos, aux_found, pending, pending_rec, pending_key;
     DevBuf sad_left, sad_right;
     uint32_t *words = nullptr; // [0] max, [1] host max staged for normalise_rows, [2] pending count, [3] next pending run
     unsigned long long *stats = nullptr; // [ring0_hits, probes]
@@ -252,35 +252,71 @@ int launch_ring(stepth_engine *e, RingArgs &ra, int qmode)
     ra.pending_count = e->words + 2;
     ra.pending_next = e->words + 32;
     ra.stats = e->stats_enabled ? e->stats : nullptr;
-    // search waves pull runs of queries from a counter, so any grid works; 8 workgroups of 4
+    TRY(reserve(e, e->pending_key, (size_t)ra.n * 4));
+
+    SearchArgs sa{};
+    sa.T = ra.T;
+    sa.BB = ra.BB;
+    sa.SB = ra.SB;
+    sa.rec = ra.pending_rec;
+    sa.key = (uint32_t *)e->pending_key.p;
+    sa.count = ra.pending_count;
+    sa.next = ra.pending_next;
+    sa.spiral = ra.spiral;
+    sa.spiral_done = ra.spiral_done;
+    sa.stats = ra.stats;
+    sa.wa = ra.wa;
+    sa.ha = ra.ha;
+    sa.bw = ra.bw;
+    sa.bh = ra.bh;
+    sa.sbw = ra.sbw;
+    sa.max_steps = ra.max_steps;
+    sa.pos_bits = ra.pos_bits;
+
+    FinishArgs fa{};
+    fa.pending = ra.pending;
+    fa.rec = ra.pending_rec;
+    fa.key = sa.key;
+    fa.count = ra.pending_count;
+    fa.pos_bits = ra.pos_bits;
+    fa.raw = ra.raw;
+    fa.raw32 = ra.raw32;
+    fa.pos = ra.pos;
+    fa.found = ra.found;
+    fa.max_word = ra.max_word;
+
+    // search waves pull runs of queries from counters, so any grid works; 8 workgroups of 4
     // waves per CU is the most that can be resident
     const uint32_t search_blocks = std::min<uint32_t>(2048u, (ra.n + 63u) / 64u);
-    // block-rings a search can reach; the LDS-staged spiral covers kSpiralRings of them
+    const uint32_t finish_blocks = std::min<uint32_t>(2048u, (ra.n + 255u) / 256u);
+    // block-rings a search can reach; the near + superblock scheme covers 33 of them
     const bool far_search =
         ((std::min(ra.max_steps, std::max(ra.wa, ra.ha)) + 6u) >> 3) > kSpiralRings;
     KernelTimer t(e);
-#define STEPTH_LAUNCH_PAIR(Q, S)                                                               \
-    do {                                                                                      \
-        hipLaunchKernelGGL((ring0_kernel<Q, S>), dim3(blocks), dim3(256), 0, e->stream, ra);  \
-        if (far_search)                                                                       \
-            hipLaunchKernelGGL((ring_search_kernel<S, true>), dim3(search_blocks), dim3(256),  \
-                               0, e->stream, ra);                                             \
-        else                                                                                  \
-            hipLaunchKernelGGL((ring_search_kernel<S, false>), dim3(search_blocks), dim3(256), \
-                               0, e->stream, ra);                                             \
-    } while (0)
-    if (e->stats_enabled) {
-        if (qmode == 0)
-            STEPTH_LAUNCH_PAIR(0, true);
+    const bool st = e->stats_enabled;
+    if (qmode == 0) {
+        if (st)
+            hipLaunchKernelGGL((ring0_kernel<0, true>), dim3(blocks), dim3(256), 0, e->stream, ra);
         else
-            STEPTH_LAUNCH_PAIR(1, true);
+            hipLaunchKernelGGL((ring0_kernel<0, false>), dim3(blocks), dim3(256), 0, e->stream, ra);
     } else {
-        if (qmode == 0)
-            STEPTH_LAUNCH_PAIR(0, false);
+        if (st)
+            hipLaunchKernelGGL((ring0_kernel<1, true>), dim3(blocks), dim3(256), 0, e->stream, ra);
         else
-            STEPTH_LAUNCH_PAIR(1, false);
+            hipLaunchKernelGGL((ring0_kernel<1, false>), dim3(blocks), dim3(256), 0, e->stream, ra);
     }
-#undef STEPTH_LAUNCH_PAIR
+    if (far_search) {
+        if (st)
+            hipLaunchKernelGGL((ring_search_kernel<true, true>), dim3(search_blocks), dim3(256), 0, e->stream, sa);
+        else
+            hipLaunchKernelGGL((ring_search_kernel<false, true>), dim3(search_blocks), dim3(256), 0, e->stream, sa);
+    } else {
+        if (st)
+            hipLaunchKernelGGL((ring_search_kernel<true, false>), dim3(search_blocks), dim3(256), 0, e->stream, sa);
+        else
+            hipLaunchKernelGGL((ring_search_kernel<false, false>), dim3(search_blocks), dim3(256), 0, e->stream, sa);
+    }
+    hipLaunchKernelGGL(ring_finish_kernel, dim3(finish_blocks), dim3(256), 0, e->stream, fa);
     HIP_TRY(e, hipGetLastError());
     return STEPTH_OK;
 }
@@ -343,7 +379,7 @@ void stepth_engine_destroy(stepth_engine *e)
     (void)hipStreamSynchronize(e->stream);
     for (DevBuf *b : {&e->T, &e->BB, &e->SB, &e->spiral, &e->stage_main, &e->stage_add, &e->stage_out,
                       &e->stage_groups, &e->queries, &e->raw, &e->aux32, &e->aux_pos,
-                      &e->aux_found, &e->pending, &e->pending_rec, &e->sad_left, &e->sad_right})
+                      &e->aux_found, &e->pending, &e->pending_rec, &e->pending_key, &e->sad_left, &e->sad_right})
         release(*b);
     if (e->words)
         (void)hipFree(e->words);

@@ -252,7 +252,7 @@ struct RingArgs {
 
 constexpr uint32_t kNoKey = 0xFFFFFFFFu;
 #ifndef STEPTH_RUN
-#define STEPTH_RUN 16
+#define STEPTH_RUN 8
 #endif
 // <= 80 SGPRs keeps 8 workgroups of 256 threads resident per CU (MI355X_MICROARCH.md,
 // "Residency"); the kernel wants ~100 without the cap
@@ -260,7 +260,10 @@ constexpr uint32_t kNoKey = 0xFFFFFFFFu;
 #define STEPTH_SEARCH_ATTR __attribute__((amdgpu_num_sgpr(80)))
 #endif
 constexpr uint32_t kRun = STEPTH_RUN; // consecutive pending queries a wave takes at a time
-constexpr uint32_t kParts = 16;      // run counters
+#ifndef STEPTH_PARTS
+#define STEPTH_PARTS 64
+#endif
+constexpr uint32_t kParts = STEPTH_PARTS; // run counters
 constexpr uint32_t kPartStride = 32; // words between counters (128-byte lines)
 
 __device__ __forceinline__ uint32_t bcast(uint32_t v, int src_lane)
@@ -431,38 +434,58 @@ __global__ __launch_bounds__(256) void ring0_kernel(RingArgs a)
     }
 }
 
-// FAR = false: max_steps <= 258 (the reference uses 255), the spiral comes from LDS only;
-// FAR = true: longer searches read the table from global memory only.  (One kernel choosing
-// between an LDS and a global pointer at run time is compiled to slow flat loads.)
-template <bool STATS, bool FAR>
-__global__ __launch_bounds__(256) STEPTH_SEARCH_ATTR void ring_search_kernel(RingArgs a)
+// The search kernel gets its own small argument block (few live scalars: it runs at 8
+// workgroups per CU only below ~80 SGPRs) and writes nothing but the winning key of every
+// pending query; ring_finish_kernel turns keys into distances.
+struct SearchArgs {
+    const uint32_t *T;
+    const uint2 *BB;
+    const uint2 *SB;
+    const Query *rec;             // pending records, compacted by ring0_kernel
+    uint32_t *key;                // out: best key per pending record (kNoKey = None)
+    const uint32_t *count;        // number of pending records
+    uint32_t *next;               // kParts run counters
+    const uint32_t *spiral;       // block-spiral table (FAR only)
+    const uint32_t *spiral_done;
+    unsigned long long *stats;
+    uint32_t wa, ha, bw, bh, sbw, max_steps, pos_bits;
+};
+
+__device__ __forceinline__ unsigned long long ballot(bool p)
 {
-    __shared__ uint32_t s_spiral[64]; // first step of the block spiral (block-rings 0..3)
-    if constexpr (!FAR) {
-        if (threadIdx.x < 64u)
-            s_spiral[threadIdx.x] = a.spiral[threadIdx.x];
-        __syncthreads();
-    }
+    return __builtin_amdgcn_ballot_w64(p);
+}
+
+// FAR = false: max_steps <= 258 (the reference uses 255): near step + superblock-guided far
+// phase.  FAR = true: longer searches walk the whole block spiral from a global table.
+template <bool STATS, bool FAR>
+__global__ __launch_bounds__(256) STEPTH_SEARCH_ATTR void ring_search_kernel(SearchArgs a)
+{
     const uint32_t lane = threadIdx.x & 63u;
     const int lx = (int)(lane & 7u), ly = (int)(lane >> 3);
     const uint32_t ring_shift = a.pos_bits + 2u;
-    const uint32_t count = *a.pending_count;
+    const uint32_t count = *a.count;
     unsigned long long n_probe = 0;
-    uint32_t wave_max = 0;
 
-    // Work is handed out dynamically in runs of kRun consecutive pending entries (one atomic
-    // per run): the cost of a query varies by two orders of magnitude, and a static split
-    // would also depend on how many workgroups are resident at once.
-    // Runs are dealt from kParts interleaved partitions (run r belongs to partition r % kParts),
-    // each with its own counter on its own cache line: one counter would cap the whole chip
-    // at ~88 grabs/us.  A wave starts at partition wave % kParts and moves on when one is empty.
+    // first step of the block spiral (slots 0..63 = block-rings 0..3 and a bit of ring 4):
+    // the same 64 blocks for every query, one per lane, kept in registers
+    int nbi, nbj;
+    block_slot(lane, nbi, nbj);
+
+    // Runs of kRun consecutive pending records are dealt from kParts interleaved partitions
+    // (run r belongs to partition r % kParts), each with its own counter on its own cache
+    // line: a single counter would cap the whole chip at ~88 grabs/us.  A wave starts at
+    // partition wave % kParts and moves on when one is empty.
     const uint32_t n_runs = (count + kRun - 1u) / kRun;
-    uint32_t part = (blockIdx.x * 4u + (threadIdx.x >> 6)) % kParts, empty = 0;
+    const uint32_t wave_id =
+        (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (threadIdx.x >> 6)));
+    uint32_t part = wave_id % kParts, empty = 0;
     for (;;) {
-        const uint32_t part_runs = (n_runs + kParts - 1u - part) / kParts; // runs r = part (mod kParts)
-        uint32_t *ctr = a.pending_next + part * kPartStride;
+        const uint32_t part_runs = (n_runs + kParts - 1u - part) / kParts;
+        uint32_t *ctr = a.next + part * kPartStride;
         uint32_t idx = part_runs;
-        if (lane == 0 && __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < part_runs)
+        if (lane == 0 &&
+            __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < part_runs)
             idx = atomicAdd(ctr, 1u);
         idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)idx);
         if (idx >= part_runs) {
@@ -474,201 +497,220 @@ __global__ __launch_bounds__(256) STEPTH_SEARCH_ATTR void ring_search_kernel(Rin
         empty = 0;
         const uint32_t run0 = (idx * kParts + part) * kRun;
         const uint32_t run_len = min(kRun, count - run0);
-        // one coalesced read brings the whole run: lane i holds query run0 + i
+        // one coalesced read brings the whole run: lane i holds record run0 + i
         Query rec = Query{0u, 0u, 0u, 0u};
-        uint32_t rq = 0;
-        if (lane < run_len) {
-            rec = a.pending_rec[run0 + lane];
-            rq = a.pending[run0 + lane];
-        }
-    for (uint32_t r = 0; r < run_len; ++r) {
-        const uint32_t q = bcast(rq, (int)r);
-        const uint32_t qx = bcast(rec.cx, (int)r), qy = bcast(rec.cy, (int)r);
-        const uint32_t qlo = bcast(rec.lo, (int)r), qhi = bcast(rec.hi, (int)r);
+        if (lane < run_len)
+            rec = a.rec[run0 + lane];
+        uint32_t result = kNoKey; // lane i: best key of record run0 + i
 
-        const uint32_t smax = max(max(qx, a.wa - 1u - qx), max(qy, a.ha - 1u - qy));
-        const uint32_t s_end = min(a.max_steps, smax + 1u); // rings 0..s_end-1 are searched
-        const int cbx = (int)(qx >> kBlkShift), cby = (int)(qy >> kBlkShift);
-        const int nox = -(int)(qx & 7u), noy = -(int)(qy & 7u);
-        const uint32_t m_end = (s_end + 6u) >> 3; // last block-ring holding a ring < s_end
-        const uint32_t u_end = (2u * m_end + 1u) * (2u * m_end + 1u);
-        const int rx = cbx * 8 - (int)qx + lx, ry = cby * 8 - (int)qy + ly; // lane's cell in
-                                                                            // block (0,0)
-        uint32_t best = kNoKey; // wave-uniform best key so far
-        uint32_t limit = s_end; // a block whose nearest cell is at ring >= limit is useless
+        for (uint32_t r = 0; r < run_len; ++r) {
+            const uint32_t qx = bcast(rec.cx, (int)r), qy = bcast(rec.cy, (int)r);
+            const uint32_t qlo = bcast(rec.lo, (int)r), qhi = bcast(rec.hi, (int)r);
+            const uint32_t smax = max(max(qx, a.wa - 1u - qx), max(qy, a.ha - 1u - qy));
+            const uint32_t s_end = min(a.max_steps, smax + 1u); // rings 0..s_end-1 are searched
+            const int cbx = (int)(qx >> kBlkShift), cby = (int)(qy >> kBlkShift);
+            const int nox = -(int)(qx & 7u), noy = -(int)(qy & 7u);
+            // lane's cell offset from the centre inside block (0,0)
+            const int rx = lx + nox, ry = ly + noy;
 
-        // One step of cell probes per surviving block (two blocks in flight): 64 lanes read
-        // its 64 cells, test them and, only if some cell matched, compute keys.  `bi,bj,dmin`
-        // are per lane (lane = block of the current step), `pm` the survivors.
-        auto probe = [&](int sbi, int sbj, uint32_t c, uint32_t &mine) {
-            const bool hit = cell_in_box(c, qlo, qhi);
-            if (__ballot(hit)) {
-                uint32_t ring;
-                const uint32_t key = scan_key(sbi * 8 + rx, sbj * 8 + ry, a.pos_bits, ring);
-                if (hit && ring < s_end)
-                    mine = min(mine, key);
-            }
-        };
-        auto probe_blocks = [&](unsigned long long pm, int bi, int bj, uint32_t dmin) {
-            while (pm) {
-                const int b0 = __ffsll(pm) - 1;
-                pm &= pm - 1;
-                const bool two = pm != 0;
-                const int b1 = two ? __ffsll(pm) - 1 : b0;
-                pm &= pm - 1; // no-op when pm == 0
-                const int i0 = (int)bcast((uint32_t)bi, b0), j0 = (int)bcast((uint32_t)bj, b0);
-                const int i1 = (int)bcast((uint32_t)bi, b1), j1 = (int)bcast((uint32_t)bj, b1);
-                const uint32_t blk0 = (uint32_t)(cby + j0) * a.bw + (uint32_t)(cbx + i0);
-                const uint32_t blk1 = (uint32_t)(cby + j1) * a.bw + (uint32_t)(cbx + i1);
-                const uint32_t c0 = a.T[blk0 * 64u + lane];
-                const uint32_t c1 = a.T[blk1 * 64u + lane];
-                uint32_t mine = kNoKey;
-                probe(i0, j0, c0, mine);
-                if (two)
-                    probe(i1, j1, c1, mine);
-                if constexpr (STATS)
-                    n_probe += two ? 128ull : 64ull;
-                if (__ballot(mine != kNoKey)) {
-                    // a match: everything farther than its ring is now useless, including
-                    // the rest of this step's survivors
-                    best = min(best, wave_min_dpp(mine));
-                    limit = min(limit, (best >> ring_shift) + 1u);
-                    pm &= __ballot(dmin < limit);
+            uint32_t best = kNoKey; // wave-uniform best key so far
+            uint32_t limit = s_end; // a block whose nearest cell is at ring >= limit is useless
+
+            // One step of cell probes per surviving block (two in flight): 64 lanes read its
+            // 64 cells (256 contiguous bytes), test them and, only if some cell matched,
+            // compute keys.  `bi,bj,dmin` are per lane (lane = block of the current step).
+            auto probe = [&](int sbi, int sbj, uint32_t c, uint32_t &mine) {
+                const bool hit = cell_in_box(c, qlo, qhi);
+                if (ballot(hit)) {
+                    uint32_t ring;
+                    const uint32_t key = scan_key(sbi * 8 + rx, sbj * 8 + ry, a.pos_bits, ring);
+                    if (hit && ring < s_end)
+                        mine = min(mine, key);
                 }
-            }
-        };
-        // smallest ring of any cell of block (bi,bj): max over axes of max(8b-o, o-8b-7, 0)
-        auto block_dmin = [&](int bi, int bj) {
-            const int ax = (bi << 3) + nox, ay = (bj << 3) + noy;
-            return (uint32_t)max(max(max(ax, -7 - ax), max(ay, -7 - ay)), 0);
-        };
-        // box [lo,hi] meets [bmin,bmax] on every channel
-        auto bounds_meet = [&](uint2 bb) {
-            return (((bb.x - qlo) & (qhi - bb.y)) | ~kGuard) == 0xFFFFFFFFu;
-        };
-
-        if constexpr (FAR) {
-            // ---- long searches (max_steps > 258): the whole block spiral, table in global ----
-            for (uint32_t u0 = 0, k = 0; u0 < u_end; u0 += 64u, ++k) {
-                const uint32_t e = a.spiral[u0 + lane];
-                const int bi = (int)(short)(e & 0xffffu), bj = (int)e >> 16;
-                const int bx = cbx + bi, by = cby + bj;
-                const uint32_t dmin = block_dmin(bi, bj);
-                bool cand = u0 + lane < u_end && (uint32_t)bx < a.bw && (uint32_t)by < a.bh &&
-                            dmin < limit;
-                if (cand)
-                    cand = bounds_meet(a.BB[(uint32_t)by * a.bw + (uint32_t)bx]);
-                if constexpr (STATS)
-                    n_probe += 64ull;
-                probe_blocks(__ballot(cand), bi, bj, dmin);
-                // block-rings 0..m_done are complete: every cell of rings <= 8 m_done has been
-                // seen or excluded
-                if (best != kNoKey && (best >> ring_shift) <= 8u * a.spiral_done[k])
-                    break;
-            }
-        } else {
-            // ---- near: the first 64 slots of the spiral = block-rings 0..3 (rings <= 24) ----
-            {
-                const uint32_t e = s_spiral[lane];
-                const int bi = (int)(short)(e & 0xffffu), bj = (int)e >> 16;
-                const int bx = cbx + bi, by = cby + bj;
-                const uint32_t dmin = block_dmin(bi, bj);
-                bool cand = lane < u_end && (uint32_t)bx < a.bw && (uint32_t)by < a.bh &&
-                            dmin < limit;
-                if (cand)
-                    cand = bounds_meet(a.BB[(uint32_t)by * a.bw + (uint32_t)bx]);
-                if constexpr (STATS)
-                    n_probe += 64ull;
-                probe_blocks(__ballot(cand), bi, bj, dmin);
-            }
-            const bool near_done = u_end <= 64u || (best != kNoKey && (best >> ring_shift) <= 24u);
-            if (!near_done) {
-                // ---- far: survey the 64x64-cell superblocks that overlap the window of
-                // radius limit-1; only those whose bounds meet the box can hold a match.
-                // Then one step per surviving superblock (nearest first): its 64 blocks.
-                const int rad = (int)limit - 1;
-                const int sx0 = max((int)qx - rad, 0) >> 6, sy0 = max((int)qy - rad, 0) >> 6;
-                const int sx1 = min((int)qx + rad, (int)a.wa - 1) >> 6;
-                const int sy1 = min((int)qy + rad, (int)a.ha - 1) >> 6;
-                const uint32_t nsx = (uint32_t)(sx1 - sx0 + 1);
-                const uint32_t nsb = nsx * (uint32_t)(sy1 - sy0 + 1); // <= 100 for rad <= 257
-                const uint32_t recip = 65535u / nsx + 1u;            // t / nsx for t < 128
-                uint32_t skey[2];
-                int ssx[2], ssy[2];
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const uint32_t t = lane + 64u * h;
-                    const uint32_t ty = (t * recip) >> 16, tx = t - ty * nsx;
-                    ssx[h] = sx0 + (int)tx;
-                    ssy[h] = sy0 + (int)ty;
-                    skey[h] = kNoKey;
-                    if (t < nsb) {
-                        const int ax = (ssx[h] << 6) - (int)qx, ay = (ssy[h] << 6) - (int)qy;
-                        const uint32_t dS =
-                            (uint32_t)max(max(max(ax, -63 - ax), max(ay, -63 - ay)), 0);
-                        if (dS < limit &&
-                            bounds_meet(a.SB[(uint32_t)ssy[h] * a.sbw + (uint32_t)ssx[h]]))
-                            skey[h] = (dS << 8) | t;
+            };
+            auto probe_blocks = [&](unsigned long long pm, int bi, int bj, uint32_t dmin) {
+                while (pm) {
+                    const int b0 = __ffsll(pm) - 1;
+                    pm &= pm - 1;
+                    const bool two = pm != 0;
+                    const int b1 = two ? __ffsll(pm) - 1 : b0;
+                    pm &= pm - 1; // no-op when pm == 0
+                    const int i0 = (int)bcast((uint32_t)bi, b0), j0 = (int)bcast((uint32_t)bj, b0);
+                    const int i1 = (int)bcast((uint32_t)bi, b1), j1 = (int)bcast((uint32_t)bj, b1);
+                    const uint32_t blk0 = (uint32_t)(cby + j0) * a.bw + (uint32_t)(cbx + i0);
+                    const uint32_t blk1 = (uint32_t)(cby + j1) * a.bw + (uint32_t)(cbx + i1);
+                    const uint32_t c0 = a.T[blk0 * 64u + lane];
+                    const uint32_t c1 = a.T[blk1 * 64u + lane];
+                    uint32_t mine = kNoKey;
+                    probe(i0, j0, c0, mine);
+                    if (two)
+                        probe(i1, j1, c1, mine);
+                    if constexpr (STATS)
+                        n_probe += two ? 128ull : 64ull;
+                    if (ballot(mine != kNoKey)) {
+                        // a match: everything farther than its ring is now useless,
+                        // including the rest of this step's survivors
+                        best = min(best, wave_min_dpp(mine));
+                        limit = min(limit, (best >> ring_shift) + 1u);
+                        pm &= ballot(dmin < limit);
                     }
                 }
-                if constexpr (STATS)
-                    n_probe += nsb > 64u ? 128ull : 64ull;
-                for (;;) {
-                    // nearest surviving superblock that can still improve the best key
-                    const uint32_t k0 = (skey[0] >> 8) < limit ? skey[0] : kNoKey;
-                    const uint32_t k1 = (skey[1] >> 8) < limit ? skey[1] : kNoKey;
-                    if (__ballot(min(k0, k1) != kNoKey) == 0)
-                        break;
-                    const uint32_t pick = wave_min_dpp(min(k0, k1));
-                    const uint32_t t = pick & 0xffu;
-                    const int owner = (int)(t & 63u);
-                    const int sx = (int)bcast((uint32_t)(t < 64u ? ssx[0] : ssx[1]), owner);
-                    const int sy = (int)bcast((uint32_t)(t < 64u ? ssy[0] : ssy[1]), owner);
-                    if (skey[0] == pick)
-                        skey[0] = kNoKey;
-                    if (skey[1] == pick)
-                        skey[1] = kNoKey;
-                    // its 64 blocks, one lane each (blocks of rings 0..3 were done above)
-                    const int bx = sx * 8 + lx, by = sy * 8 + ly;
-                    const int bi = bx - cbx, bj = by - cby;
+            };
+            // smallest ring of any cell of block (bi,bj): max over axes of max(8b-o, o-8b-7, 0)
+            auto block_dmin = [&](int bi, int bj) {
+                const int ax = (bi << 3) + nox, ay = (bj << 3) + noy;
+                return (uint32_t)max(max(max(ax, -7 - ax), max(ay, -7 - ay)), 0);
+            };
+            // box [lo,hi] meets [bmin,bmax] on every channel
+            auto bounds_meet = [&](uint2 bb) {
+                return (((bb.x - qlo) & (qhi - bb.y)) | ~kGuard) == 0xFFFFFFFFu;
+            };
+
+            if constexpr (FAR) {
+                const uint32_t m_end = (s_end + 6u) >> 3; // last block-ring with a ring < s_end
+                const uint32_t u_end = (2u * m_end + 1u) * (2u * m_end + 1u);
+                for (uint32_t u0 = 0, k = 0; u0 < u_end; u0 += 64u, ++k) {
+                    const uint32_t e = a.spiral[u0 + lane];
+                    const int bi = (int)(short)(e & 0xffffu), bj = (int)e >> 16;
+                    const int bx = cbx + bi, by = cby + bj;
                     const uint32_t dmin = block_dmin(bi, bj);
-                    bool cand = (uint32_t)bx < a.bw && (uint32_t)by < a.bh && dmin < limit &&
-                                max(abs(bi), abs(bj)) > 3;
+                    bool cand = u0 + lane < u_end && (uint32_t)bx < a.bw &&
+                                (uint32_t)by < a.bh && dmin < limit;
                     if (cand)
                         cand = bounds_meet(a.BB[(uint32_t)by * a.bw + (uint32_t)bx]);
                     if constexpr (STATS)
                         n_probe += 64ull;
-                    probe_blocks(__ballot(cand), bi, bj, dmin);
+                    probe_blocks(ballot(cand), bi, bj, dmin);
+                    // block-rings 0..m_done are complete: every cell of rings <= 8 m_done has
+                    // been seen or excluded
+                    if (best != kNoKey && (best >> ring_shift) <= 8u * a.spiral_done[k])
+                        break;
+                }
+            } else {
+                // ---- near: block-rings 0..3 (all cells of rings <= 24) ----
+                {
+                    const int bx = cbx + nbi, by = cby + nbj;
+                    const uint32_t dmin = block_dmin(nbi, nbj);
+                    bool cand = (uint32_t)bx < a.bw && (uint32_t)by < a.bh && dmin < limit;
+                    if (cand)
+                        cand = bounds_meet(a.BB[(uint32_t)by * a.bw + (uint32_t)bx]);
+                    if constexpr (STATS)
+                        n_probe += 64ull;
+                    probe_blocks(ballot(cand), nbi, nbj, dmin);
+                }
+                // rings <= 24 are settled; anything farther needs the far phase
+                if (s_end > 25u && !(best != kNoKey && (best >> ring_shift) <= 24u)) {
+                    // ---- far: survey the 64x64-cell superblocks overlapping the window of
+                    // radius limit-1 -- only those whose bounds meet the box can hold a match
+                    // -- then one step per surviving superblock, nearest first: its 64 blocks.
+                    const int rad = (int)limit - 1;
+                    const int sx0 = max((int)qx - rad, 0) >> 6, sy0 = max((int)qy - rad, 0) >> 6;
+                    const int sx1 = min((int)qx + rad, (int)a.wa - 1) >> 6;
+                    const int sy1 = min((int)qy + rad, (int)a.ha - 1) >> 6;
+                    const int nsx = sx1 - sx0 + 1, nsy = sy1 - sy0 + 1; // <= 10 each
+                    // superblock t of the window sits at (t % 16, t / 16): 3 rounds cover 16 x 12
+                    uint32_t skey[3] = {kNoKey, kNoKey, kNoKey};
+#pragma unroll
+                    for (int h = 0; h < 3; ++h) {
+                        const int tx = (int)(lane & 15u), ty = (int)(lane >> 4) + 4 * h;
+                        if (tx < nsx && ty < nsy) {
+                            const int sx = sx0 + tx, sy = sy0 + ty;
+                            const int ax = (sx << 6) - (int)qx, ay = (sy << 6) - (int)qy;
+                            const uint32_t dS =
+                                (uint32_t)max(max(max(ax, -63 - ax), max(ay, -63 - ay)), 0);
+                            if (dS < limit && bounds_meet(a.SB[(uint32_t)sy * a.sbw + (uint32_t)sx]))
+                                skey[h] = (dS << 8) | (uint32_t)(ty * 16 + tx);
+                        }
+                        if (4 * (h + 1) >= nsy)
+                            break;
+                    }
+                    if constexpr (STATS)
+                        n_probe += 64ull;
+                    for (;;) {
+                        // nearest surviving superblock that can still improve the best key
+                        uint32_t k = min(min(skey[0], skey[1]), skey[2]);
+                        k = (k >> 8) < limit ? k : kNoKey;
+                        if (ballot(k != kNoKey) == 0)
+                            break;
+                        const uint32_t pick = wave_min_dpp(k);
+                        const int sx = sx0 + (int)(pick & 15u), sy = sy0 + (int)((pick >> 4) & 15u);
+#pragma unroll
+                        for (int h = 0; h < 3; ++h)
+                            skey[h] = skey[h] == pick ? kNoKey : skey[h];
+                        // its 64 blocks, one lane each (block-rings 0..3 were done above)
+                        const int bx = sx * 8 + lx, by = sy * 8 + ly;
+                        const int bi = bx - cbx, bj = by - cby;
+                        const uint32_t dmin = block_dmin(bi, bj);
+                        bool cand = (uint32_t)bx < a.bw && (uint32_t)by < a.bh && dmin < limit &&
+                                    max(abs(bi), abs(bj)) > 3;
+                        if (cand)
+                            cand = bounds_meet(a.BB[(uint32_t)by * a.bw + (uint32_t)bx]);
+                        if constexpr (STATS)
+                            n_probe += 64ull;
+                        probe_blocks(ballot(cand), bi, bj, dmin);
+                    }
                 }
             }
+            if (lane == r)
+                result = best;
         }
-
-        // distance (helpers.rs:3-7), u8 wrap (depth_image.rs:121); None stays 0 from ring0
-        if (best != kNoKey) {
-            int fdx, fdy;
-            key_to_offset(best, a.pos_bits, fdx, fdy);
-            const uint32_t d = isqrt_floor((uint32_t)(fdx * fdx + fdy * fdy));
-            wave_max = max(wave_max, d & 0xffu);
-            if (lane == 0) {
-                a.raw[q] = (uint8_t)(d & 0xffu);
-                if (a.raw32)
-                    a.raw32[q] = d;
-                if (a.pos) {
-                    a.pos[2 * (size_t)q] = (uint32_t)((int)qx + fdx);
-                    a.pos[2 * (size_t)q + 1] = (uint32_t)((int)qy + fdy);
-                }
-                if (a.found)
-                    a.found[q] = 1;
-            }
-        }
+        if (lane < run_len)
+            a.key[run0 + lane] = result;
     }
-    }
-    if (lane == 0) { // global max, depth_image.rs:124
-        if (wave_max)
-            atomicMax(a.max_word, wave_max);
-        if constexpr (STATS)
+    if constexpr (STATS) {
+        if (lane == 0)
             atomicAdd(&a.stats[1], n_probe);
     }
+}
+
+// keys -> distances: helpers.rs:3-7 (floor sqrt), depth_image.rs:121 (`d as u8` wraps),
+// :124 (max).  Dense over the pending records; None keeps the 0 written by ring0_kernel.
+struct FinishArgs {
+    const uint32_t *pending; // query ids
+    const Query *rec;
+    const uint32_t *key;
+    const uint32_t *count;
+    uint32_t pos_bits;
+    uint8_t *raw;
+    uint32_t *raw32, *pos;
+    uint8_t *found;
+    uint32_t *max_word;
+};
+
+__global__ __launch_bounds__(256) void ring_finish_kernel(FinishArgs a)
+{
+    __shared__ uint32_t s_max;
+    if (threadIdx.x == 0)
+        s_max = 0;
+    __syncthreads();
+    const uint32_t count = *a.count;
+    uint32_t mx = 0;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < count; i += gridDim.x * 256u) {
+        const uint32_t key = a.key[i];
+        if (key == kNoKey)
+            continue;
+        const uint32_t q = a.pending[i];
+        int dx, dy;
+        key_to_offset(key, a.pos_bits, dx, dy);
+        const uint32_t d = isqrt_floor((uint32_t)(dx * dx + dy * dy));
+        a.raw[q] = (uint8_t)(d & 0xffu);
+        mx = max(mx, d & 0xffu);
+        if (a.raw32)
+            a.raw32[q] = d;
+        if (a.pos) {
+            const Query r = a.rec[i];
+            a.pos[2 * (size_t)q] = (uint32_t)((int)r.cx + dx);
+            a.pos[2 * (size_t)q + 1] = (uint32_t)((int)r.cy + dy);
+        }
+        if (a.found)
+            a.found[q] = 1;
+    }
+    mx = wave_max_u32(mx);
+    if ((threadIdx.x & 63u) == 0 && mx)
+        atomicMax(&s_max, mx);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_max)
+        atomicMax(a.max_word, s_max);
 }
 
 // ---------------------------------------------------------------------------------------
