@@ -105,6 +105,11 @@ typedef struct {
     uint64_t groups;       /* groups (queries) processed */
     uint64_t ring0_hits;   /* groups that matched at their centre cell */
     uint64_t probes;       /* predicate evaluations issued by the kernels (lane-granular) */
+    /* wave-steps of the search kernel by kind (each = 64 lane-probes) */
+    uint64_t near_steps;       /* block tests of block-rings 0..3 (or spiral steps)          */
+    uint64_t survey_steps;     /* superblock surveys                                          */
+    uint64_t superblock_steps; /* block tests inside a surviving superblock                   */
+    uint64_t blocks_probed;    /* 8x8 blocks whose 64 cells were read                         */
 } stepth_stats;
 
 uint32_t stepth_abi_version(void);

@@ -52,7 +52,9 @@ class Params(C.Structure):
 
 
 class Stats(C.Structure):
-    _fields_ = [("groups", C.c_uint64), ("ring0_hits", C.c_uint64), ("probes", C.c_uint64)]
+    _fields_ = [("groups", C.c_uint64), ("ring0_hits", C.c_uint64), ("probes", C.c_uint64),
+                ("near_steps", C.c_uint64), ("survey_steps", C.c_uint64),
+                ("superblock_steps", C.c_uint64), ("blocks_probed", C.c_uint64)]
 
 
 # every symbol include/stepth_amd.h declares: name -> (restype, argtypes)

@@ -22,7 +22,7 @@ using namespace stepth;
 
 static_assert(sizeof(stepth_group) == 20 && sizeof(GroupRec) == 20, "group layout");
 static_assert(sizeof(Query) == 16, "query layout");
-static_assert(sizeof(stepth_params) == 44 && sizeof(stepth_image) == 32 && sizeof(stepth_stats) == 24,
+static_assert(sizeof(stepth_params) == 44 && sizeof(stepth_image) == 32 && sizeof(stepth_stats) == 56,
               "C-ABI struct layout (mirrored by stepth_amd/_lib.py)");
 
 namespace {
@@ -630,7 +630,7 @@ int stepth_depth_from_additional(stepth_engine *e, const stepth_image *main_im,
         TRY(reserve(e, e->raw, std::max<size_t>(ra.n, 4)));
         ra.raw = static_cast<uint8_t *>(e->raw.p);
         if (e->stats_enabled) {
-            HIP_TRY(e, hipMemsetAsync(e->stats, 0, 16, e->stream));
+            HIP_TRY(e, hipMemsetAsync(e->stats, 0, 64, e->stream));
             e->stats_groups = ra.n;
         }
         TRY(launch_ring(e, ra, qmode));
@@ -787,7 +787,7 @@ int stepth_distance_dot_array_batch(stepth_engine *e, const stepth_image *array,
     ra.found = (uint8_t *)e->aux_found.p;
     ra.max_word = e->words;
     if (e->stats_enabled) {
-        HIP_TRY(e, hipMemsetAsync(e->stats, 0, 16, e->stream));
+        HIP_TRY(e, hipMemsetAsync(e->stats, 0, 64, e->stream));
         e->stats_groups = n;
     }
     TRY(launch_ring(e, ra, 1));
@@ -804,7 +804,7 @@ int stepth_stats_enable(stepth_engine *e, int enable)
         return STEPTH_ERR_BAD_ARG;
     e->stats_enabled = enable != 0;
     e->stats_groups = 0;
-    HIP_TRY(e, hipMemsetAsync(e->stats, 0, 16, e->stream));
+    HIP_TRY(e, hipMemsetAsync(e->stats, 0, 64, e->stream));
     return STEPTH_OK;
 }
 
@@ -814,12 +814,16 @@ int stepth_get_stats(stepth_engine *e, stepth_stats *out)
         return STEPTH_ERR_BAD_ARG;
     if (!e->stats_enabled)
         return fail(e, STEPTH_ERR_BAD_ARG, "stats are not enabled (stepth_stats_enable)");
-    unsigned long long h[2] = {0, 0};
-    HIP_TRY(e, hipMemcpyAsync(h, e->stats, 16, hipMemcpyDeviceToHost, e->stream));
+    unsigned long long h[8] = {0};
+    HIP_TRY(e, hipMemcpyAsync(h, e->stats, 64, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     out->groups = e->stats_groups;
     out->ring0_hits = h[0];
     out->probes = h[1];
+    out->near_steps = h[2];
+    out->survey_steps = h[3];
+    out->superblock_steps = h[4];
+    out->blocks_probed = h[5];
     return STEPTH_OK;
 }
 

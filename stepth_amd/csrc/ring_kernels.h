@@ -465,7 +465,7 @@ __global__ __launch_bounds__(256) STEPTH_SEARCH_ATTR void ring_search_kernel(Sea
     const int lx = (int)(lane & 7u), ly = (int)(lane >> 3);
     const uint32_t ring_shift = a.pos_bits + 2u;
     const uint32_t count = *a.count;
-    unsigned long long n_probe = 0;
+    unsigned long long n_probe = 0, n_near = 0, n_survey = 0, n_super = 0, n_blocks = 0;
 
     // first step of the block spiral (slots 0..63 = block-rings 0..3 and a bit of ring 4):
     // the same 64 blocks for every query, one per lane, kept in registers
@@ -545,8 +545,10 @@ __global__ __launch_bounds__(256) STEPTH_SEARCH_ATTR void ring_search_kernel(Sea
                     probe(i0, j0, c0, mine);
                     if (two)
                         probe(i1, j1, c1, mine);
-                    if constexpr (STATS)
+                    if constexpr (STATS) {
                         n_probe += two ? 128ull : 64ull;
+                        n_blocks += two ? 2ull : 1ull;
+                    }
                     if (ballot(mine != kNoKey)) {
                         // a match: everything farther than its ring is now useless,
                         // including the rest of this step's survivors
@@ -594,8 +596,10 @@ __global__ __launch_bounds__(256) STEPTH_SEARCH_ATTR void ring_search_kernel(Sea
                     bool cand = (uint32_t)bx < a.bw && (uint32_t)by < a.bh && dmin < limit;
                     if (cand)
                         cand = bounds_meet(a.BB[(uint32_t)by * a.bw + (uint32_t)bx]);
-                    if constexpr (STATS)
+                    if constexpr (STATS) {
                         n_probe += 64ull;
+                        ++n_near;
+                    }
                     probe_blocks(ballot(cand), nbi, nbj, dmin);
                 }
                 // rings <= 24 are settled; anything farther needs the far phase
@@ -624,8 +628,10 @@ __global__ __launch_bounds__(256) STEPTH_SEARCH_ATTR void ring_search_kernel(Sea
                         if (4 * (h + 1) >= nsy)
                             break;
                     }
-                    if constexpr (STATS)
+                    if constexpr (STATS) {
                         n_probe += 64ull;
+                        ++n_survey;
+                    }
                     for (;;) {
                         // nearest surviving superblock that can still improve the best key
                         uint32_t k = min(min(skey[0], skey[1]), skey[2]);
@@ -645,8 +651,10 @@ __global__ __launch_bounds__(256) STEPTH_SEARCH_ATTR void ring_search_kernel(Sea
                                     max(abs(bi), abs(bj)) > 3;
                         if (cand)
                             cand = bounds_meet(a.BB[(uint32_t)by * a.bw + (uint32_t)bx]);
-                        if constexpr (STATS)
+                        if constexpr (STATS) {
                             n_probe += 64ull;
+                            ++n_super;
+                        }
                         probe_blocks(ballot(cand), bi, bj, dmin);
                     }
                 }
@@ -658,8 +666,13 @@ __global__ __launch_bounds__(256) STEPTH_SEARCH_ATTR void ring_search_kernel(Sea
             a.key[run0 + lane] = result;
     }
     if constexpr (STATS) {
-        if (lane == 0)
+        if (lane == 0) {
             atomicAdd(&a.stats[1], n_probe);
+            atomicAdd(&a.stats[2], n_near);
+            atomicAdd(&a.stats[3], n_survey);
+            atomicAdd(&a.stats[4], n_super);
+            atomicAdd(&a.stats[5], n_blocks);
+        }
     }
 }
 

@@ -218,8 +218,7 @@ class Engine:
     def stats(self) -> dict:
         s = L.Stats()
         self._check(self._lib.stepth_get_stats(self._h, C.byref(s)))
-        return {"groups": int(s.groups), "ring0_hits": int(s.ring0_hits),
-                "probes": int(s.probes)}
+        return {k: int(getattr(s, k)) for k, _t in L.Stats._fields_}
 
     def kernel_time_enable(self, on: bool = True):
         self._check(self._lib.stepth_kernel_time_enable(self._h, int(on)))
