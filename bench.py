@@ -8,8 +8,8 @@ Workload (BASELINE.json metric: "Mpixels/sec depth output, 1080p stereo d_max=12
   a step = one pass of the hot path over a batch of `frames_per_gpu * N` synthetic 1920x1080
   stereo pairs (inputs resident in HBM), reference-exact mode (square-ring first hit,
   /root/reference/src/helpers.rs:9-54), one group per pixel, max_steps = d_max = 128,
-  precision [36;3] (Readme.md:14).  Per frame: pack additional -> ring_match -> max ->
-  normalise -> depth rows.  With N > 1 every frame is sharded by row strips over the N ranks,
+  precision [36;3] (Readme.md:14).  Per frame: pack additional -> ring0 (centre cell + compaction)
+  -> ring_search -> ring_finish (distance, max) -> normalise -> depth rows.  With N > 1 every frame is sharded by row strips over the N ranks,
   with one all_reduce(MAX) and one all_gather of depth rows per step (RCCL); per-GPU work is
   constant in N (weak scaling).  value = frames * 1920*1080 / step time, whole job.
 
@@ -17,7 +17,7 @@ Workload (BASELINE.json metric: "Mpixels/sec depth output, 1080p stereo d_max=12
   reference and is reported under its own metric name.
 
 roofline: HBM-bound by contract (scan/compare, no MFMA).  achieved = algorithmic bytes per
-  ring_match launch (7 B per output pixel: 3 B main RGB + 3 B additional RGB + 1 B depth,
+  ring_search launch (7 B per output pixel: 3 B main RGB + 3 B additional RGB + 1 B depth,
   SURVEY.md 8d) / that kernel's mean launch time, measured live with HIP events on the
   engine's stream; peak = 8 TB/s.  The ring search is data dependent, so the mean number of
   probes per pixel is printed next to it.
@@ -110,6 +110,9 @@ def main():
     ap.add_argument("--precision", type=int, default=36)
     ap.add_argument("--frames-per-gpu", dest="fpg", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl",
+                    help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
+                         "the multi-rank path with several ranks on one GPU)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -122,11 +125,16 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the hot path has no CPU fallback")
+    if args.backend != "nccl":  # rehearsal: ranks share whatever GPUs exist
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     from stepth_amd import MODE_RING_FIRST_HIT, MODE_SAD_WINDOW, Engine
     from stepth_amd.sharding import EngineStripWorker, sharded_depth, strip_bounds
@@ -192,6 +200,14 @@ def main():
         px_launch = (strip_rows[1] - strip_rows[0]) * W
         k_avg_ms = kms / max(klaunches, 1)
         achieved = ALGO_BYTES_PER_PIXEL * px_launch / (k_avg_ms * 1e-3) / 1e9 if klaunches else 0.0
+        # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE,
+        # gfx950-corrected; see profiles/r1_ring_hbm_traffic.json) -- only for the profiled shape
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r1_ring_hbm_traffic.json")
+        if args.mode == "ring" and world == 1 and (W, H, args.d_max) == (1920, 1080, 128) \
+                and os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get(
+                "ring_search_kernel_traffic_bytes_per_launch_corrected")
         out = {
             "metric": ("Mpixels/sec depth output, 1080p stereo d_max=128" if args.mode == "ring"
                        else "Mpixels/sec depth output, windowed-SAD mode (not in the reference)"),
@@ -215,8 +231,8 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
-                "kernel": "ring_match_kernel" if args.mode == "ring" else "sad_match_kernel",
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                "kernel": "ring_search_kernel" if args.mode == "ring" else "sad_match_kernel",
                 "kernel_avg_ms": round(k_avg_ms, 4), "kernel_launches": klaunches,
                 "algorithmic_bytes_per_launch": ALGO_BYTES_PER_PIXEL * px_launch,
                 "probes_per_pixel": None if probes_pp is None else round(probes_pp, 1),

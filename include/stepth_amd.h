@@ -171,7 +171,7 @@ int stepth_stats_enable(stepth_engine *engine, int enable);
 int stepth_get_stats(stepth_engine *engine, stepth_stats *out);
 
 /*
- * Timing hook for bench.py's roofline leg: brackets the dominant kernel (ring_match or
+ * Timing hook for bench.py's roofline leg: brackets the dominant kernel (ring_search or
  * sad_match) of every subsequent call with HIP events on the engine's stream and
  * accumulates; stepth_kernel_time_read() synchronises and returns the sum in milliseconds
  * and the number of launches, then resets.

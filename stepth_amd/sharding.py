@@ -96,10 +96,17 @@ def sharded_depth(worker: StripWorker, frames: Sequence, height: int, width: int
     if device is None:
         device = maxes[0].device
     max_all = torch.cat([m.reshape(1) for m in maxes]).to(torch.int32)
+    # gloo (CPU rehearsals of the N > 1 path) cannot gather device tensors: stage through host
+    via_host = world > 1 and dist.get_backend(group) == "gloo" and max_all.is_cuda
     if world > 1:
         if sync:
             sync()
-        dist.all_reduce(max_all, op=dist.ReduceOp.MAX, group=group)  # src/depth_image.rs:124
+        if via_host:
+            m_host = max_all.cpu()
+            dist.all_reduce(m_host, op=dist.ReduceOp.MAX, group=group)
+            max_all = m_host.to(device)
+        else:
+            dist.all_reduce(max_all, op=dist.ReduceOp.MAX, group=group)  # src/depth_image.rs:124
     for i, raw in enumerate(strips):
         worker.normalise(raw, max_all[i:i + 1])  # src/depth_image.rs:125-129
 
@@ -113,7 +120,12 @@ def sharded_depth(worker: StripWorker, frames: Sequence, height: int, width: int
     recv = torch.empty((world, n, rows_max, width), dtype=torch.uint8, device=device)
     if sync:
         sync()
-    dist.all_gather_into_tensor(recv.view(-1), send.view(-1), group=group)
+    if via_host:
+        r_host = torch.empty(recv.shape, dtype=torch.uint8)
+        dist.all_gather_into_tensor(r_host.view(-1), send.cpu().view(-1), group=group)
+        recv.copy_(r_host)
+    else:
+        dist.all_gather_into_tensor(recv.view(-1), send.view(-1), group=group)
     depth = torch.empty((n, height, width), dtype=torch.uint8, device=device)
     for r, (a, b) in enumerate(bounds):
         if b > a:
