@@ -64,7 +64,10 @@ enum {
     /* stop after PASS 1 (src/depth_image.rs:112-123): write the painted, un-normalised
      * (d as u8) map; used by row-strip sharding, where the max is reduced across ranks
      * before stepth_normalise_rows() */
-    STEPTH_FLAG_RAW_ONLY = 1u << 1
+    STEPTH_FLAG_RAW_ONLY = 1u << 1,
+    /* also apply the tail of the reference, src/depth_image.rs:133-134: a same-size resample
+     * with image's Gaussian filter (full-frame calls only; parity unpinned) */
+    STEPTH_FLAG_GAUSSIAN_TAIL = 1u << 2
 };
 
 /* disage::DiscretePixel{position{x,y}, size{width,height}, value:[u8;3]} as consumed at
@@ -151,6 +154,14 @@ int stepth_depth_from_additional(stepth_engine *engine, const stepth_image *main
  */
 int stepth_normalise_rows(stepth_engine *engine, const stepth_image *rows,
                           const uint32_t *max_ptr, uint32_t max_memory, uint32_t flags);
+
+/*
+ * The tail alone, src/depth_image.rs:133-134: DynamicImage::resize(w, h, Gaussian) of a Luma8
+ * image to its own size (a 7-tap separable blur).  src and dst have the same size and may be
+ * the same buffer.  Used after the gather in the sharded flow.
+ */
+int stepth_gaussian_same_size(stepth_engine *engine, const stepth_image *src,
+                              const stepth_image *dst, uint32_t flags);
 
 /*
  * helpers::distance_dot_array for a batch of independent queries, src/helpers.rs:9-54:

@@ -37,8 +37,8 @@ def build(force: bool = False, lib_path: str = _LIB_PATH, march: Optional[str] =
             and os.path.getmtime(lib_path) >= max(os.path.getmtime(src),
                                                   os.path.getmtime(src[:-2] + ".h"))):
         return lib_path
-    cmd = ["gcc", "-O3", f"-march={march or 'x86-64-v2'}", "-fPIC", "-Wall", "-Wextra",
-           "-std=c11", "-D_POSIX_C_SOURCE=200809L", src, "-o", lib_path, "-shared", "-lm",
+    cmd = ["gcc", "-O3", f"-march={march or 'x86-64-v2'}", "-ffp-contract=off", "-fPIC", "-Wall",
+           "-Wextra", "-std=c11", "-D_DEFAULT_SOURCE", src, "-o", lib_path, "-shared", "-lm",
            "-lpthread"]
     subprocess.run(cmd, check=True)
     return lib_path
@@ -83,6 +83,9 @@ def lib(path: Optional[str] = None):
     L.oracle_sad_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_size_t,
                                   C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, u8p,
                                   C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
+    L.oracle_gaussian_same_size.restype = None
+    L.oracle_gaussian_same_size.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_size_t,
+                                            C.c_void_p, C.c_size_t]
     L.oracle_hardware_threads.restype = C.c_int
     L.oracle_set_threads.restype = None
     L.oracle_set_threads.argtypes = [C.c_int]
@@ -206,6 +209,16 @@ def sad_rows(left: np.ndarray, right: np.ndarray, d_max: int, win: int, precisio
                                threads, raw.ctypes.data)
     assert rc == OK, rc
     return raw
+
+
+def gaussian_same_size(img: np.ndarray) -> np.ndarray:
+    """src/depth_image.rs:133-134 (image 0.23.14 sampler restated from memory; unpinned)"""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    assert img.ndim == 2
+    out = np.zeros_like(img)
+    h, w = img.shape
+    lib().oracle_gaussian_same_size(img.ctypes.data, w, h, img.strides[0], out.ctypes.data, w)
+    return out
 
 
 def hardware_threads() -> int:

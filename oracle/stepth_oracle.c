@@ -356,6 +356,64 @@ int oracle_depth_from_additional(const uint8_t *main_px, uint32_t w, uint32_t h,
     return rc;
 }
 
+/* ---- Gaussian same-size resample, src/depth_image.rs:133-134 (image 0.23.14; unpinned) ---- */
+
+static float gauss05(float x)
+{ /* image::imageops::sample::gaussian(x, 0.5); evaluated in double and rounded once, so that
+   * the value does not depend on whose expf() is used (libm, compile-time folding, GPU) */
+    const double r = 0.5, xd = (double)x;
+    return (float)((1.0 / (sqrt(2.0 * 3.14159265358979323846) * r)) * exp(-(xd * xd) / (2.0 * r * r)));
+}
+
+/* one pass along an axis of length n: taps for output o are inputs [left, right) */
+static void gauss_pass(const uint8_t *src, size_t s_elem, size_t s_line, uint32_t n,
+                       uint32_t lines, uint8_t *dst, size_t d_elem, size_t d_line)
+{
+    for (uint32_t o = 0; o < n; ++o) {
+        const float in_c = ((float)o + 0.5f) * 1.0f;
+        int64_t left = (int64_t)floorf(in_c - 3.0f);
+        if (left < 0)
+            left = 0;
+        if (left > (int64_t)n - 1)
+            left = (int64_t)n - 1;
+        int64_t right = (int64_t)ceilf(in_c + 3.0f);
+        if (right < left + 1)
+            right = left + 1;
+        if (right > (int64_t)n)
+            right = (int64_t)n;
+        const float centre = in_c - 0.5f;
+        float ws[8], sum = 0.0f;
+        const int taps = (int)(right - left);
+        for (int i = 0; i < taps; ++i) {
+            ws[i] = gauss05((float)(left + i) - centre);
+            sum += ws[i];
+        }
+        for (int i = 0; i < taps; ++i)
+            ws[i] /= sum;
+        for (uint32_t l = 0; l < lines; ++l) {
+            float t = 0.0f;
+            for (int i = 0; i < taps; ++i)
+                t += (float)src[(size_t)l * s_line + (size_t)(left + i) * s_elem] * ws[i];
+            if (t < 0.0f)
+                t = 0.0f;
+            if (t > 255.0f)
+                t = 255.0f;
+            dst[(size_t)l * d_line + (size_t)o * d_elem] = (uint8_t)roundf(t);
+        }
+    }
+}
+
+void oracle_gaussian_same_size(const uint8_t *src, uint32_t w, uint32_t h, size_t sstride,
+                               uint8_t *dst, size_t dstride)
+{
+    uint8_t *tmp = (uint8_t *)malloc((size_t)w * h);
+    /* vertical_sample: axis = rows, lines = columns */
+    gauss_pass(src, sstride, 1, h, w, tmp, w, 1);
+    /* horizontal_sample */
+    gauss_pass(tmp, 1, w, w, h, dst, 1, dstride);
+    free(tmp);
+}
+
 /* ---- windowed-SAD mode: not in the reference; the engine's own second mode ---- */
 
 typedef struct {

@@ -97,6 +97,16 @@ int oracle_depth_from_additional(const uint8_t *main_px, uint32_t w, uint32_t h,
                                  uint8_t *depth, uint8_t *raw_out, uint8_t *max_out,
                                  uint64_t *probes);
 
+/* The tail of load_depth_from_additional, src/depth_image.rs:133-134:
+ * DynamicImage::resize(w, h, imageops::Gaussian) to the SAME size.  image 0.23.14 is not in
+ * the reference tree, so this follows its published sampler from memory (vertical pass then
+ * horizontal pass; kernel gaussian(x, 0.5) with support 3 -> taps i in [o-3, o+3], window
+ * clipped at the borders, weights normalised by their sum, f32 accumulation in tap order,
+ * round-half-away to u8 after each pass): PARITY UNPINNED -- checked only by tolerance
+ * against assets/depth.jpg. */
+void oracle_gaussian_same_size(const uint8_t *src, uint32_t w, uint32_t h, size_t sstride,
+                               uint8_t *dst, size_t dstride);
+
 /* Windowed-SAD mode (north_star's literal description; NOT in the reference; self-oracle).
  * cost(x,y,d) = sum over win x win window, 3 channels of |L(x+i,y+j) - R(x+i-d,y+j)| with
  * clamp-to-edge coordinates; raw = smallest d in [0,d_max) with cost < win*win*(p0+p1+p2),

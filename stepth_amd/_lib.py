@@ -30,6 +30,7 @@ MEM_HOST = 0
 MEM_DEVICE = 1
 FLAG_ASYNC = 1
 FLAG_RAW_ONLY = 2
+FLAG_GAUSSIAN_TAIL = 4
 
 
 class Group(C.Structure):
@@ -73,6 +74,7 @@ SYMBOLS = {
                                                C.c_void_p]),
     "stepth_normalise_rows": (C.c_int, [C.c_void_p, _P(Image), C.c_void_p, C.c_uint32,
                                         C.c_uint32]),
+    "stepth_gaussian_same_size": (C.c_int, [C.c_void_p, _P(Image), _P(Image), C.c_uint32]),
     "stepth_distance_dot_array_batch": (C.c_int, [C.c_void_p, _P(Image), C.c_void_p, C.c_void_p,
                                                   C.c_size_t, C.c_uint32, C.c_void_p,
                                                   C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -47,7 +48,7 @@ struct stepth_engine {
     DevBuf T, BB, SB;      // packed additional image: tiled cells, block / superblock bounds
     DevBuf stage_main, stage_add, stage_out, stage_groups;
     DevBuf queries, raw, aux32, aux_pos, aux_found, pending, pending_rec, pending_key;
-    DevBuf sad_left, sad_right;
+    DevBuf sad_left, sad_right, gauss_tmp, gauss_io;
     uint32_t *words = nullptr; // [0] max, [1] host max staged for normalise_rows, [2] pending count, [3] next pending run
     unsigned long long *stats = nullptr; // [ring0_hits, probes]
     DevBuf spiral;                       // block-spiral table + per-chunk complete rings
@@ -323,6 +324,59 @@ int launch_ring(stepth_engine *e, RingArgs &ra, int qmode)
     return STEPTH_OK;
 }
 
+// image::imageops::sample::gaussian(x, 0.5) and the per-border-class tap weights of a
+// same-size resample (support 3): taps with offsets cl-3 .. 3-cr, normalised by their sum
+void gaussian_weights(float w[4][4][7])
+{
+    for (int cl = 0; cl < 4; ++cl)
+        for (int cr = 0; cr < 4; ++cr) {
+            float sum = 0.0f;
+            for (int k = 0; k < 7; ++k)
+                w[cl][cr][k] = 0.0f;
+            for (int k = cl - 3; k <= 3 - cr; ++k) {
+                // in double, rounded once: independent of any particular expf()
+                const double x = (double)k, r = 0.5;
+                const float g = (float)((1.0 / (std::sqrt(2.0 * 3.14159265358979323846) * r)) *
+                                        std::exp(-(x * x) / (2.0 * r * r)));
+                w[cl][cr][k + 3] = g;
+                sum += g;
+            }
+            for (int k = cl - 3; k <= 3 - cr; ++k)
+                w[cl][cr][k + 3] /= sum;
+        }
+}
+
+// vertical pass src -> gauss_tmp, horizontal pass gauss_tmp -> dst (device pointers)
+int gaussian_device(stepth_engine *e, const uint8_t *src, size_t sstride, uint32_t w, uint32_t h,
+                    uint8_t *dst, size_t dstride)
+{
+    TRY(reserve(e, e->gauss_tmp, (size_t)w * h));
+    GaussArgs ga{};
+    gaussian_weights(ga.w);
+    const size_t total = (size_t)w * h;
+    const uint32_t blocks = (uint32_t)std::min<size_t>((total + 255) / 256, 4096);
+    ga.src = src;
+    ga.s_elem = sstride; // vertical_sample: along rows
+    ga.s_line = 1;
+    ga.n = h;
+    ga.lines = w;
+    ga.dst = (uint8_t *)e->gauss_tmp.p;
+    ga.d_elem = w;
+    ga.d_line = 1;
+    hipLaunchKernelGGL(gauss_pass_kernel, dim3(blocks), dim3(256), 0, e->stream, ga);
+    ga.src = (const uint8_t *)e->gauss_tmp.p; // horizontal_sample
+    ga.s_elem = 1;
+    ga.s_line = w;
+    ga.n = w;
+    ga.lines = h;
+    ga.dst = dst;
+    ga.d_elem = 1;
+    ga.d_line = dstride;
+    hipLaunchKernelGGL(gauss_pass_kernel, dim3(blocks), dim3(256), 0, e->stream, ga);
+    HIP_TRY(e, hipGetLastError());
+    return STEPTH_OK;
+}
+
 } // namespace
 
 extern "C" {
@@ -381,7 +435,7 @@ void stepth_engine_destroy(stepth_engine *e)
     (void)hipStreamSynchronize(e->stream);
     for (DevBuf *b : {&e->T, &e->BB, &e->SB, &e->spiral, &e->stage_main, &e->stage_add, &e->stage_out,
                       &e->stage_groups, &e->queries, &e->raw, &e->aux32, &e->aux_pos,
-                      &e->aux_found, &e->pending, &e->pending_rec, &e->pending_key, &e->sad_left, &e->sad_right})
+                      &e->aux_found, &e->pending, &e->pending_rec, &e->pending_key, &e->sad_left, &e->sad_right, &e->gauss_tmp, &e->gauss_io})
         release(*b);
     if (e->words)
         (void)hipFree(e->words);
@@ -659,6 +713,13 @@ int stepth_depth_from_additional(stepth_engine *e, const stepth_image *main_im,
         return fail(e, STEPTH_ERR_BAD_ARG, "unknown mode %u", p.mode);
     }
 
+    if (p.flags & STEPTH_FLAG_GAUSSIAN_TAIL) { // src/depth_image.rs:133-134
+        if (raw_only || row0 != 0 || row1 != H)
+            return fail(e, STEPTH_ERR_BAD_ARG,
+                        "STEPTH_FLAG_GAUSSIAN_TAIL needs a full-frame, normalised call");
+        TRY(gaussian_device(e, d_out, os, W, H, d_out, os));
+    }
+
     if (async) {
         if (max_out)
             HIP_TRY(e, hipMemcpyAsync(max_out, e->words, 4, hipMemcpyDeviceToDevice, e->stream));
@@ -731,6 +792,43 @@ int stepth_normalise_rows(stepth_engine *e, const stepth_image *rows, const uint
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     if (mx_host == 0)
         return fail(e, STEPTH_ERR_MAX_ZERO, "max is 0; rows zeroed");
+    return STEPTH_OK;
+}
+
+int stepth_gaussian_same_size(stepth_engine *e, const stepth_image *src, const stepth_image *dst,
+                              uint32_t flags)
+{
+    if (!e)
+        return STEPTH_ERR_BAD_ARG;
+    TRY(check_image(e, src, "src", 1, 1));
+    TRY(check_image(e, dst, "dst", 1, 1));
+    if (src->width != dst->width || src->height != dst->height)
+        return fail(e, STEPTH_ERR_SIZE_MISMATCH, "Sizes don't match");
+    const bool async = flags & STEPTH_FLAG_ASYNC;
+    if (async && (src->memory != STEPTH_MEM_DEVICE || dst->memory != STEPTH_MEM_DEVICE))
+        return fail(e, STEPTH_ERR_BAD_ARG, "STEPTH_FLAG_ASYNC needs device memory everywhere");
+    HIP_TRY(e, hipSetDevice(e->device));
+    const uint32_t W = src->width, H = src->height;
+    const uint8_t *d_src = nullptr;
+    size_t ss = 0;
+    TRY(to_device(e, *src, e->gauss_io, d_src, ss));
+    uint8_t *d_dst;
+    size_t ds;
+    if (dst->memory == STEPTH_MEM_DEVICE) {
+        d_dst = static_cast<uint8_t *>(const_cast<void *>(dst->data));
+        ds = dst->stride;
+    } else {
+        ds = (W + 15u) & ~(size_t)15;
+        TRY(reserve(e, e->stage_out, ds * H));
+        d_dst = static_cast<uint8_t *>(e->stage_out.p);
+    }
+    TRY(gaussian_device(e, d_src, ss, W, H, d_dst, ds));
+    if (async)
+        return STEPTH_OK;
+    if (dst->memory == STEPTH_MEM_HOST)
+        HIP_TRY(e, hipMemcpy2DAsync(const_cast<void *>(dst->data), dst->stride, d_dst, ds, W, H,
+                                    hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
     return STEPTH_OK;
 }
 

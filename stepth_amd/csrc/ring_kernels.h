@@ -829,6 +829,48 @@ __global__ __launch_bounds__(256) void normalise_rows_kernel(NormArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Gaussian same-size resample, the tail of load_depth_from_additional
+// (src/depth_image.rs:133-134: DynamicImage::resize(w, h, imageops::Gaussian)).  image 0.23.14
+// is not part of the reference tree; this follows its sampler as published (vertical pass,
+// then horizontal pass; gaussian(x, 0.5), support 3 -> taps o-3..o+3 clipped at the borders
+// and renormalised; f32 accumulation in tap order; round-half-away to u8 after each pass).
+// PARITY UNPINNED: checked against the oracle bit for bit and against assets/depth.jpg only
+// by tolerance.  Weights come from the host (16 border classes x 7 taps) so that CPU and GPU
+// use the very same floats.
+// ---------------------------------------------------------------------------------------
+struct GaussArgs {
+    const uint8_t *src;
+    size_t s_elem, s_line; // strides along the filtered axis / between lines
+    uint32_t n, lines;
+    uint8_t *dst;
+    size_t d_elem, d_line;
+    float w[4][4][7]; // [clipped taps before][clipped taps after][offset + 3]
+};
+
+__global__ __launch_bounds__(256) void gauss_pass_kernel(GaussArgs a)
+{
+// the reference accumulates t += v * w in f32 with separate roundings; HIP's __fmul_rn /
+// __fadd_rn are plain operators, so contraction into FMA has to be switched off here
+#pragma clang fp contract(off)
+    const size_t total = (size_t)a.n * a.lines;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        // consecutive threads run along the contiguous direction of the destination
+        const uint32_t o = a.d_elem == 1 ? (uint32_t)(i % a.n) : (uint32_t)(i / a.lines);
+        const uint32_t l = a.d_elem == 1 ? (uint32_t)(i / a.n) : (uint32_t)(i % a.lines);
+        const int cl = max(0, 3 - (int)o), cr = max(0, (int)o + 3 - (int)(a.n - 1));
+        const float *w = a.w[min(cl, 3)][min(cr, 3)];
+        float t = 0.0f;
+        for (int k = cl - 3; k <= 3 - cr; ++k) {
+            const float v = (float)a.src[(size_t)l * a.s_line + (size_t)((int)o + k) * a.s_elem];
+            t = t + v * w[k + 3];
+        }
+        t = fminf(fmaxf(t, 0.0f), 255.0f);
+        a.dst[(size_t)l * a.d_line + (size_t)o * a.d_elem] = (uint8_t)roundf(t);
+    }
+}
+
 __global__ void zero_words_kernel(uint32_t *p, int n)
 {
     if ((int)threadIdx.x < n)

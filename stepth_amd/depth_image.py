@@ -139,14 +139,16 @@ class DepthImage:
     def load_depth_from_additional(self, add_image, precision: Sequence[int], *,
                                    groups: Optional[np.ndarray] = None,
                                    tile: Tuple[int, int] = (1, 1), max_steps: int = 255,
+                                   gaussian_tail: bool = True,
                                    engine: Optional[Engine] = None) -> None:
         """Runs the whole path on the GPU and stores the result in `self.depth`.
 
         `precision` is the reference's `[u8;3]`.  Keyword options are what the reference
         hard-codes or delegates to disage: `groups` (a GROUP_DTYPE array standing in for
         disage::open::rgb_discrete's output, :104-110; default: uniform `tile`s, 1x1 = one
-        group per pixel) and `max_steps` (the literal 255 at :119).  The Gaussian resample
-        of :133-134 is not applied (parity unpinned).
+        group per pixel) and `max_steps` (the literal 255 at :119).  `gaussian_tail` applies
+        the same-size Gaussian resample of :133-134 like the reference does (image 0.23.14's
+        sampler restated -- parity unpinned); pass False for the bare depth map.
 
         Where the reference panics on a zero maximum (:127) this raises MaxZeroError and
         leaves `self.depth` all zero."""
@@ -155,7 +157,8 @@ class DepthImage:
         try:
             depth, _mx = eng.depth_from_additional(self.image, add, precision,
                                                    max_steps=max_steps, tile=tile,
-                                                   groups=groups, mode=L.MODE_RING_FIRST_HIT)
+                                                   groups=groups, mode=L.MODE_RING_FIRST_HIT,
+                                                   gaussian_tail=gaussian_tail)
         except MaxZeroError:
             self.depth = np.zeros(self.image.shape[:2], np.uint8)
             raise

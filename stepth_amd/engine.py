@@ -125,7 +125,8 @@ class Engine:
                               tile: Tuple[int, int] = (1, 1), groups=None,
                               mode: int = L.MODE_RING_FIRST_HIT, d_max: int = 0, win: int = 0,
                               rows: Optional[Tuple[int, int]] = None, raw_only: bool = False,
-                              out=None, max_out=None, asynchronous: bool = False):
+                              gaussian_tail: bool = False, out=None, max_out=None,
+                              asynchronous: bool = False):
         """stepth_depth_from_additional.  Returns (depth [H,W] u8, max or None).
 
         numpy in -> numpy out (synchronous).  torch CUDA tensors in -> tensor out; with
@@ -155,7 +156,8 @@ class Engine:
             p.row_begin, p.row_end = rows
             if rows[0] == rows[1]:
                 return out, 0  # empty strip; 0,0 would mean "all rows" in the C-ABI
-        p.flags = (L.FLAG_ASYNC if asynchronous else 0) | (L.FLAG_RAW_ONLY if raw_only else 0)
+        p.flags = ((L.FLAG_ASYNC if asynchronous else 0) | (L.FLAG_RAW_ONLY if raw_only else 0) |
+                   (L.FLAG_GAUSSIAN_TAIL if gaussian_tail else 0))
         gptr, gn, gmem, k4 = None, 0, L.MEM_HOST, None
         if groups is not None:
             if _is_tensor(groups):
@@ -192,6 +194,20 @@ class Engine:
                                                  flags)
         self._check(st)
         return rows
+
+    def gaussian_same_size(self, src, out=None, asynchronous: bool = False):
+        """stepth_gaussian_same_size: the reference's `.resize(w, h, Gaussian)` tail."""
+        si, _k1 = _describe(src, (1,), "src")
+        if out is None:
+            if _is_tensor(src):
+                import torch
+                out = torch.empty_like(src)
+            else:
+                out = np.zeros((si.height, si.width), np.uint8)
+        di, _k2 = _describe(out, (1,), "dst")
+        self._check(self._lib.stepth_gaussian_same_size(
+            self._h, C.byref(si), C.byref(di), L.FLAG_ASYNC if asynchronous else 0))
+        return out
 
     def distance_dot_array_batch(self, array, what, from_xy, max_steps: int, precision):
         """helpers::distance_dot_array for n queries -> (found u8[n], dist u32[n], pos u32[n,2])."""

@@ -357,9 +357,42 @@ def test_depth_image_mirror_end_to_end(engine, oracle, asset, tmp_path):
     img = DepthImage.open(str(pm))
     img.open_depth_from_additional(str(pa), [255 // 7] * 3, engine=engine)
     ref = oracle.depth_from_additional(asset["main"], asset["additional"], P36)
-    np.testing.assert_array_equal(img.depth, ref["depth"])
+    # the mirror applies the Gaussian tail like the reference (:133-134; parity unpinned)
+    np.testing.assert_array_equal(img.depth, oracle.gaussian_same_size(ref["depth"]))
     d = img.depth.astype(float)
-    assert np.corrcoef(d.ravel(), asset["depth"].astype(float).ravel())[0, 1] >= 0.975
+    assert np.corrcoef(d.ravel(), asset["depth"].astype(float).ravel())[0, 1] >= 0.985
+    img.open_depth_from_additional(str(pa), [36] * 3, engine=engine, gaussian_tail=False)
+    np.testing.assert_array_equal(img.depth, ref["depth"])
+
+
+@pytest.mark.parametrize("w,h", [(600, 400), (1, 1), (3, 2), (2, 9), (64, 7), (257, 131)])
+def test_gaussian_tail_matches_oracle(engine, oracle, w, h):
+    rng = np.random.default_rng(w * 31 + h)
+    img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    img[rng.random((h, w)) < 0.5] = 0  # depth maps are mostly flat with sharp steps
+    np.testing.assert_array_equal(engine.gaussian_same_size(img), oracle.gaussian_same_size(img))
+    strided = np.zeros((h, w + 5), np.uint8)
+    strided[:, :w] = img
+    out = np.full((h, w + 3), 9, np.uint8)
+    engine.gaussian_same_size(strided[:, :w], out=out[:, :w])
+    np.testing.assert_array_equal(out[:, :w], oracle.gaussian_same_size(img))
+    assert (out[:, w:] == 9).all()
+
+
+def test_gaussian_tail_flag_and_device_path(engine, oracle):
+    import torch
+    from stepth_amd import StepthError, synth
+    l, r, _ = synth.stereo_pair(210, 130, 32, seed=6)
+    ref = oracle.gaussian_same_size(oracle.depth_from_additional(l, r, P36)["depth"])
+    d, _ = engine.depth_from_additional(l, r, P36, gaussian_tail=True)
+    np.testing.assert_array_equal(d, ref)
+    dl, dr = torch.from_numpy(l).cuda(), torch.from_numpy(r).cuda()
+    dd, _ = engine.depth_from_additional(dl, dr, P36, gaussian_tail=True)
+    np.testing.assert_array_equal(dd.cpu().numpy(), ref)
+    bare, _ = engine.depth_from_additional(dl, dr, P36)
+    np.testing.assert_array_equal(engine.gaussian_same_size(bare).cpu().numpy(), ref)
+    with pytest.raises(StepthError):  # strips cannot blur across their seams
+        engine.depth_from_additional(l, r, P36, gaussian_tail=True, rows=(0, 64))
 
 
 def test_full_size_properties_1080p(engine):

@@ -203,3 +203,21 @@ def test_sad_oracle_recovers_planted_disparity(oracle):
     raw = oracle.sad_rows(l, r, 24, 5, [0, 0, 0])  # threshold 0 -> pure argmin
     inner = (slice(4, -4), slice(40, -8))
     assert (np.abs(raw[inner].astype(int) - disp[inner]) <= 1).mean() > 0.7  # measured 0.78
+
+
+def test_gaussian_same_size_known_answers(oracle):
+    """gaussian(x, 0.5) taps at offsets -3..3, normalised: [1.5e-8, 2.7e-4, 0.1065, 0.7866, ...]"""
+    flat = np.full((5, 7), 200, np.uint8)
+    assert (oracle.gaussian_same_size(flat) == 200).all()          # weights sum to 1, also
+    imp = np.zeros((9, 9), np.uint8)                                # at the clipped borders
+    imp[4, 4] = 255
+    out = oracle.gaussian_same_size(imp)
+    # vertical pass: round(255*0.7866)=201, round(255*0.1065)=27; then horizontal on those
+    assert out[4, 4] == round(201 * 0.78656) and out[4, 3] == out[4, 5] == round(201 * 0.10645)
+    assert out[3, 4] == out[5, 4] == round(27 * 0.78656) and out[3, 3] == round(27 * 0.10645)
+    assert out[0].sum() == 0 and out[:, 0].sum() == 0
+    one = np.array([[77]], np.uint8)
+    assert oracle.gaussian_same_size(one)[0, 0] == 77
+    row = np.arange(0, 250, 10, dtype=np.uint8)[None, :]
+    out = oracle.gaussian_same_size(row)
+    assert out.shape == row.shape and abs(int(out[0, 12]) - 120) <= 1
