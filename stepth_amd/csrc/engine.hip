@@ -554,6 +554,18 @@ int stepth_depth_from_additional(stepth_engine *e, const stepth_image *main_im,
             sa.thr = p.win * p.win * ((uint32_t)p.precision[0] + p.precision[1] + p.precision[2]);
             sa.raw = static_cast<uint8_t *>(e->raw.p);
             sa.max_word = e->words;
+            if (sad_has_fast_path(sa.win)) {
+                uint32_t prow = 0;
+                int apron = 0;
+                sad_plane_dims(sa, false, sa.lpitch, prow, apron);
+                TRY(reserve(e, e->sad_left, (size_t)sa.lpitch * prow * 4));
+                sad_plane_dims(sa, true, sa.rpitch, prow, apron);
+                TRY(reserve(e, e->sad_right, (size_t)sa.rpitch * prow * 4));
+                sa.lp = (uint32_t *)e->sad_left.p;
+                sa.rp = (uint32_t *)e->sad_right.p;
+                if (launch_sad_pack(sa, e->stream) != STEPTH_OK)
+                    return fail(e, STEPTH_ERR_HIP, "sad_pack launch failed");
+            }
             {
                 KernelTimer t(e);
                 int s = launch_sad(sa, e->stream);

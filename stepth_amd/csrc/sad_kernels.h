@@ -5,6 +5,21 @@
 // checked only against the engine's own CPU statement (oracle_sad_rows):
 //   cost(x,y,d) = sum_{win x win} sum_c |L(x+i,y+j)_c - R(x+i-d,y+j)_c|   (clamp-to-edge)
 //   raw(x,y)    = smallest d in [0,d_max) with cost < win^2 (p0+p1+p2), else first argmin.
+//
+// Layout: both images are first packed into RGBX dword planes with an apron that bakes the
+// clamp-to-edge rule in (left apron rad [+ d_max-1 for R], right apron rad + 64, rad rows
+// above and below), so the search kernel never clamps an index.
+//
+// sad_search_kernel<WIN, DC>: one wave = 64 adjacent columns x kSadRows output rows.  Lane x
+// owns column x.  For a chunk of DC disparities it walks down the input rows; per row it
+// reads the WIN left cells and the DC+WIN-1 right cells its column needs (consecutive lanes
+// read consecutive dwords), forms the horizontal window sums H(d) with WIN chained v_sad_u8
+// per disparity -- neighbouring disparities reuse the same registers shifted by one -- and
+// keeps the vertical window as cost(d) += H_new(d) - H_old(d) with the last WIN rows of H in
+// a register ring (the row loop is unrolled WIN times so the ring is indexed statically).
+// The per-pixel decision (first d under the threshold, else first argmin) is carried from
+// chunk to chunk in LDS; a strip whose pixels are all decided by the threshold stops early.
+// No cross-lane traffic apart from that one ballot per chunk.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -22,9 +37,10 @@ struct SadArgs {
     uint32_t d_max, win, thr;
     uint8_t *raw; // [(row1-row0)][w]
     uint32_t *max_word;
+    // packed planes (sad_pack_kernel)
+    uint32_t *lp, *rp;
+    uint32_t lpitch, rpitch; // dwords
 };
-
-constexpr int kSadTileW = 64, kSadTileH = 4;
 
 __device__ __forceinline__ uint32_t load_rgbx(const uint8_t *img, size_t stride, uint32_t ch,
                                               int x, int y, int w, int h)
@@ -35,8 +51,131 @@ __device__ __forceinline__ uint32_t load_rgbx(const uint8_t *img, size_t stride,
     return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
 }
 
-// One thread per output pixel, tile 64 x 4; L and R windows staged in LDS as RGBX dwords so
-// that v_sad_u8 does one pixel's three channel differences (plus a zero byte) per issue.
+// plane[yy][xx] = RGBX(img[clamp(yy - rad)][clamp(xx - apron_l)])
+struct SadPackArgs {
+    const uint8_t *img;
+    size_t stride;
+    uint32_t ch, w, h;
+    int rad, apron_l;
+    uint32_t pitch, rows;
+    uint32_t *plane;
+};
+
+__global__ __launch_bounds__(256) void sad_pack_kernel(SadPackArgs a)
+{
+    const size_t total = (size_t)a.pitch * a.rows;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int yy = (int)(i / a.pitch), xx = (int)(i % a.pitch);
+        a.plane[i] = load_rgbx(a.img, a.stride, a.ch, xx - a.apron_l, yy - a.rad, a.w, a.h);
+    }
+}
+
+constexpr int kSadRows = 16; // output rows per wave
+constexpr int kSadPadD = 16; // extra left apron of the R plane: the last chunk of DC
+                             // disparities may run past d_max (those costs are ignored)
+
+template <int WIN, int DC>
+__global__ __launch_bounds__(256) void sad_search_kernel(SadArgs a)
+{
+    constexpr int RAD = WIN / 2;
+    __shared__ uint32_t s_best[4][kSadRows][64]; // running min cost
+    __shared__ uint32_t s_pick[4][kSadRows][64]; // bit 31: decided (under threshold); low: d
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int x = ((int)blockIdx.x * 4 + wv) * 64 + lane;          // output column
+    const int ys = (int)a.row0 + (int)blockIdx.y * kSadRows;       // first output row
+    const int nrows = min(kSadRows, (int)a.row1 - ys);
+    if (((int)blockIdx.x * 4 + wv) * 64 >= (int)a.w) // whole wave outside (uniform)
+        return;
+#pragma unroll
+    for (int r = 0; r < kSadRows; ++r) {
+        s_best[wv][r][lane] = 0xffffffffu;
+        s_pick[wv][r][lane] = 0u;
+    }
+    // plane coordinates: image (x', y') sits at [y' + RAD][x' + apron_l]
+    const uint32_t *lcol = a.lp + x;                         // + i  -> L(x - RAD + i)
+    for (int d0 = 0; d0 < (int)a.d_max; d0 += DC) {
+        // + k -> R(x - RAD + i - d) with k = i + (DC-1-j), d = d0 + j
+        const uint32_t *rcol = a.rp + x + kSadPadD + ((int)a.d_max - 1) - d0 - (DC - 1);
+        uint32_t cost[DC], ring[WIN][DC];
+#pragma unroll
+        for (int j = 0; j < DC; ++j) {
+            cost[j] = 0;
+#pragma unroll
+            for (int s = 0; s < WIN; ++s)
+                ring[s][j] = 0;
+        }
+        // input rows ys-RAD .. ys+nrows-1+RAD, i.e. plane rows ys .. ys+nrows-1+2*RAD
+        const int n_in = nrows + 2 * RAD;
+        for (int t0 = 0; t0 < n_in; t0 += WIN) {
+#pragma unroll
+            for (int s = 0; s < WIN; ++s) {
+                const int t = t0 + s;
+                if (t < n_in) { // uniform
+                    const uint32_t *lr = lcol + (size_t)(ys + t) * a.lpitch;
+                    const uint32_t *rr = rcol + (size_t)(ys + t) * a.rpitch;
+                    uint32_t l[WIN], r[DC + WIN - 1];
+#pragma unroll
+                    for (int i = 0; i < WIN; ++i)
+                        l[i] = lr[i];
+#pragma unroll
+                    for (int k = 0; k < DC + WIN - 1; ++k)
+                        r[k] = rr[k];
+#pragma unroll
+                    for (int j = 0; j < DC; ++j) {
+                        uint32_t hsum = 0;
+#pragma unroll
+                        for (int i = 0; i < WIN; ++i)
+                            hsum = __builtin_amdgcn_sad_u8(l[i], r[i + DC - 1 - j], hsum);
+                        cost[j] += hsum - ring[s][j];
+                        ring[s][j] = hsum;
+                    }
+                    const int orow = t - 2 * RAD; // output row (relative) completed by this input row
+                    if (orow >= 0) {
+                        uint32_t best = s_best[wv][orow][lane], pick = s_pick[wv][orow][lane];
+#pragma unroll
+                        for (int j = 0; j < DC; ++j) {
+                            const uint32_t d = (uint32_t)(d0 + j), c = cost[j];
+                            const bool live = (int)pick >= 0 && d < a.d_max;
+                            if (live && c < a.thr)
+                                pick = 0x80000000u | d; // first disparity under the threshold
+                            else if (live && c < best) {
+                                best = c;
+                                pick = d;
+                            }
+                        }
+                        s_best[wv][orow][lane] = best;
+                        s_pick[wv][orow][lane] = pick;
+                    }
+                }
+            }
+        }
+        // every pixel of the strip already decided by the threshold: later disparities
+        // cannot change anything
+        bool open = false;
+        for (int r = 0; r < nrows; ++r)
+            open |= (int)s_pick[wv][r][lane] >= 0;
+        if (__builtin_amdgcn_ballot_w64(open) == 0)
+            break;
+    }
+    uint32_t m = 0;
+    if (x < (int)a.w) {
+        for (int r = 0; r < nrows; ++r) {
+            const uint32_t d = s_pick[wv][r][lane] & 0xffffu;
+            a.raw[(size_t)(ys - (int)a.row0 + r) * a.w + x] = (uint8_t)d;
+            m = max(m, d & 0xffu);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+    if (lane == 0 && m)
+        atomicMax(a.max_word, m);
+}
+
+// ---- generic fallback (any odd window up to 15): one thread per pixel, windows in LDS ----
+constexpr int kSadTileW = 64, kSadTileH = 4;
+
 __global__ __launch_bounds__(256) void sad_match_kernel(SadArgs a)
 {
     extern __shared__ uint32_t lds[];
@@ -96,8 +235,52 @@ __global__ __launch_bounds__(256) void sad_match_kernel(SadArgs a)
         atomicMax(a.max_word, m);
 }
 
+inline bool sad_has_fast_path(uint32_t win) { return win == 3 || win == 5 || win == 7 || win == 9; }
+
+inline void sad_plane_dims(const SadArgs &a, bool right, uint32_t &pitch, uint32_t &rows,
+                           int &apron_l)
+{
+    const int rad = (int)a.win / 2;
+    apron_l = rad + (right ? (int)a.d_max - 1 + kSadPadD : 0);
+    pitch = (uint32_t)(apron_l + (int)((a.w + 63u) / 64u * 64u) + rad + 64);
+    rows = a.h + 2u * (uint32_t)rad;
+}
+
+// pack both planes; a.lp/a.rp/pitches must already be set
+inline int launch_sad_pack(const SadArgs &a, hipStream_t stream)
+{
+    for (int side = 0; side < 2; ++side) {
+        SadPackArgs p{};
+        p.img = side ? a.right : a.left;
+        p.stride = side ? a.rstride : a.lstride;
+        p.ch = side ? 3u : a.lch;
+        p.w = a.w;
+        p.h = a.h;
+        p.rad = (int)a.win / 2;
+        uint32_t pitch, rows;
+        sad_plane_dims(a, side != 0, pitch, rows, p.apron_l);
+        p.pitch = pitch;
+        p.rows = rows;
+        p.plane = side ? a.rp : a.lp;
+        const size_t total = (size_t)pitch * rows;
+        const uint32_t blocks = (uint32_t)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+        hipLaunchKernelGGL(sad_pack_kernel, dim3(blocks), dim3(256), 0, stream, p);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
 inline int launch_sad(const SadArgs &a, hipStream_t stream)
 {
+    if (sad_has_fast_path(a.win)) {
+        dim3 grid((a.w + 255) / 256, (a.row1 - a.row0 + kSadRows - 1) / kSadRows);
+        switch (a.win) {
+        case 3: hipLaunchKernelGGL((sad_search_kernel<3, 16>), grid, dim3(256), 0, stream, a); break;
+        case 5: hipLaunchKernelGGL((sad_search_kernel<5, 16>), grid, dim3(256), 0, stream, a); break;
+        case 7: hipLaunchKernelGGL((sad_search_kernel<7, 8>), grid, dim3(256), 0, stream, a); break;
+        default: hipLaunchKernelGGL((sad_search_kernel<9, 8>), grid, dim3(256), 0, stream, a); break;
+        }
+        return hipGetLastError() == hipSuccess ? 0 : -3;
+    }
     const int rad = (int)a.win / 2;
     const int lw = kSadTileW + 2 * rad, rw = lw + (int)a.d_max - 1, th = kSadTileH + 2 * rad;
     const size_t lds = (size_t)(lw + rw) * th * 4;
