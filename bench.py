@@ -10,7 +10,7 @@ Workload (BASELINE.json metric: "Mpixels/sec depth output, 1080p stereo d_max=12
   /root/reference/src/helpers.rs:9-54), one group per pixel, max_steps = d_max = 128,
   precision [36;3] (Readme.md:14).  Per frame: pack additional -> ring0 (centre cell + compaction)
   -> ring_search -> ring_finish (distance, max) -> normalise -> depth rows.  With N > 1 every frame is sharded by row strips over the N ranks,
-  with one all_reduce(MAX) and one all_gather of depth rows per step (RCCL); per-GPU work is
+  with one all_reduce(MAX) and one gather of the depth rows to rank 0 per step (RCCL); per-GPU work is
   constant in N (weak scaling).  value = frames * 1920*1080 / step time, whole job.
 
   --mode sad runs the windowed-SAD mode (5x5, d_max=128) instead; it has no counterpart in the
@@ -154,7 +154,7 @@ def main():
         worker = EngineStripWorker(eng, prec, mode=MODE_SAD_WINDOW, d_max=args.d_max, win=args.win)
 
     def step():
-        return sharded_depth(worker, frames, H, W)
+        return sharded_depth(worker, frames, H, W, dst=0 if world > 1 else None)
 
     def fence():
         torch.cuda.synchronize()
@@ -226,7 +226,7 @@ def main():
                              + f", precision [{args.precision};3]"),
                 "frames_per_step": n_frames, "width": W, "height": H, "d_max": args.d_max,
                 "mode": args.mode,
-                "parallelism": (f"row strips x{world} + all_reduce(max) + all_gather (RCCL)"
+                "parallelism": (f"row strips x{world} + all_reduce(max) + gather of rows to rank 0 (RCCL)"
                                 if world > 1 else "single GPU"),
             },
             "roofline": {

@@ -6,7 +6,7 @@ a frame shards by main-image row strips with exactly one real exchange:
 
     PASS 1 on the rank's strip  ->  all_reduce(MAX) of one word per frame
                                 ->  PASS 2 on the strip (stepth_normalise_rows)
-                                ->  all_gather of the u8 depth rows
+                                ->  gather (or all_gather) of the u8 depth rows
 
 `torch.distributed` is plumbing (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in
 the CPU tests).  The two compute steps are injected as callables so that the collective
@@ -75,11 +75,14 @@ class EngineStripWorker(StripWorker):
 def sharded_depth(worker: StripWorker, frames: Sequence, height: int, width: int,
                   tile_h: int = 1, group: Optional[dist.ProcessGroup] = None,
                   device: Optional[torch.device] = None,
-                  sync: Optional[Callable[[], None]] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+                  sync: Optional[Callable[[], None]] = None,
+                  dst: Optional[int] = None) -> Tuple[Optional[torch.Tensor], torch.Tensor]:
     """Depth maps of `frames`, every frame row-strip sharded over the ranks of `group`.
 
-    Returns (depth u8 [F, H, W], max int32 [F]) on every rank.  Collectives per call (not
-    per frame): one all_reduce(MAX) of F words and one all_gather of F*rows_per_rank*W bytes.
+    Returns (depth u8 [F, H, W], max int32 [F]).  Collectives per call (not per frame): one
+    all_reduce(MAX) of F words and one exchange of the u8 rows -- `dst=None`: all_gather, every
+    rank gets the depth maps; `dst=r`: gather to rank r only (the other ranks return None;
+    each sends its own F*rows*W bytes over its own xGMI link to r, nothing else moves).
     `sync` is called before each collective when the worker computes on a side stream."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -117,15 +120,24 @@ def sharded_depth(worker: StripWorker, frames: Sequence, height: int, width: int
     if r1 > r0:
         for i, raw in enumerate(strips):
             send[i, : r1 - r0] = raw
-    recv = torch.empty((world, n, rows_max, width), dtype=torch.uint8, device=device)
     if sync:
         sync()
-    if via_host:
-        r_host = torch.empty(recv.shape, dtype=torch.uint8)
-        dist.all_gather_into_tensor(r_host.view(-1), send.cpu().view(-1), group=group)
-        recv.copy_(r_host)
+    if dst is not None:
+        coll_dev = torch.device("cpu") if via_host else device
+        parts = ([torch.empty((n, rows_max, width), dtype=torch.uint8, device=coll_dev)
+                  for _ in range(world)] if rank == dst else None)
+        dist.gather(send.cpu() if via_host else send, parts, dst=dst, group=group)
+        if rank != dst:
+            return None, max_all
+        recv = torch.stack(parts).to(device)
     else:
-        dist.all_gather_into_tensor(recv.view(-1), send.view(-1), group=group)
+        recv = torch.empty((world, n, rows_max, width), dtype=torch.uint8, device=device)
+        if via_host:
+            r_host = torch.empty(recv.shape, dtype=torch.uint8)
+            dist.all_gather_into_tensor(r_host.view(-1), send.cpu().view(-1), group=group)
+            recv.copy_(r_host)
+        else:
+            dist.all_gather_into_tensor(recv.view(-1), send.view(-1), group=group)
     depth = torch.empty((n, height, width), dtype=torch.uint8, device=device)
     for r, (a, b) in enumerate(bounds):
         if b > a:

@@ -50,7 +50,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, tile, q):
+def _worker(rank, world, port, tile, q, dst=None):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -62,21 +62,22 @@ def _worker(rank, world, port, tile, q):
             l, r, _ = synth.stereo_pair(97, 61, 16, seed=seed)
             frames.append((l, r))
         wk = OracleStripWorker([36] * 3, 64, tile)
-        depth, mx = sharded_depth(wk, frames, 61, 97, tile_h=tile[1])
-        q.put((rank, depth.numpy(), mx.numpy()))
+        depth, mx = sharded_depth(wk, frames, 61, 97, tile_h=tile[1], dst=dst)
+        assert (depth is None) == (dst is not None and rank != dst)
+        q.put((rank, None if depth is None else depth.numpy(), mx.numpy()))
         dist.barrier()
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,tile", [(2, (1, 1)), (3, (1, 1)), (2, (5, 5))])
-def test_sharded_equals_single_process(world, tile):
+@pytest.mark.parametrize("world,tile,dst", [(2, (1, 1), None), (3, (1, 1), 0), (2, (5, 5), 1)])
+def test_sharded_equals_single_process(world, tile, dst):
     from oracle import oracle as O
     from stepth_amd import synth
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, tile, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, tile, q, dst)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=180) for _ in range(world)]
@@ -87,8 +88,10 @@ def test_sharded_equals_single_process(world, tile):
         l, r, _ = synth.stereo_pair(97, 61, 16, seed=seed)
         ref = O.depth_from_additional(l, r, [36] * 3, 64, tile)
         for rank, depth, mx in results:
-            np.testing.assert_array_equal(depth[seed_i], ref["depth"])
+            if depth is not None:
+                np.testing.assert_array_equal(depth[seed_i], ref["depth"])
             assert int(mx[seed_i]) == ref["max"]
+    assert sum(d is not None for _r, d, _m in results) == (world if dst is None else 1)
 
 
 def test_single_process_path_without_init():
