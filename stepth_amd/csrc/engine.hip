@@ -228,7 +228,8 @@ int launch_ring(stepth_engine *e, RingArgs &ra, int qmode)
 {
     if (ra.n == 0)
         return STEPTH_OK;
-    const uint32_t blocks = (ra.n + 256u * kRing0Iters - 1u) / (256u * kRing0Iters);
+    const uint32_t slots = qmode == 0 ? ra.n_slots : ra.n;
+    const uint32_t blocks = (slots + 256u * kRing0Iters - 1u) / (256u * kRing0Iters);
     TRY(ensure_spiral(e, ra.max_steps, ra.wa, ra.ha));
     {
         // 32-bit scan keys: ring | side(2) | position; sized for the farthest reachable ring
@@ -668,6 +669,12 @@ int stepth_depth_from_additional(stepth_engine *e, const stepth_image *main_im,
                 ra.mch = main_im->channels;
                 ra.w = W;
                 ra.row0 = row0;
+                ra.row1 = row1;
+                // 2x2 tiles anchored at odd coordinates: tile (tx,ty) = pixels 2tx-1..2tx x
+                // 2ty-1..2ty, all of which have middle (tx,ty)
+                ra.ntx = (W >> 1) + 1u;
+                ra.ty0 = (row0 + 1u) >> 1;
+                ra.n_slots = rows ? ra.ntx * ((row1 >> 1) - ra.ty0 + 1u) * 4u : 0u;
                 qmode = 0;
             } else {
                 TRY(reserve(e, e->queries, (size_t)std::max(ra.n, 1u) * sizeof(Query)));

@@ -228,7 +228,8 @@ struct RingArgs {
     // QMODE 0: one query per main pixel (uniform 1x1 tiles), read straight from the image
     const uint8_t *main_px;
     size_t mstride;
-    uint32_t mch, w, row0;
+    uint32_t mch, w, row0, row1;
+    uint32_t ntx, ty0, n_slots; // 2x2 tiles of the strip: columns, first tile row, slots
     // QMODE 1: prepared queries
     const Query *queries;
     uint32_t n;
@@ -334,23 +335,40 @@ STEPTH_HD void block_slot(uint32_t u, int &i, int &j)
 // (2m+1)^2 <= done
 STEPTH_HD uint32_t rings_done(uint32_t done) { return (isqrt_floor(done) - 1u) >> 1; }
 
+// Query `slot` of a launch -> its id q (index into raw), centre and colour box.
+// QMODE 0 (one query per main pixel): slots walk the image in 2x2 tiles anchored at odd
+// coordinates -- the four pixels (2tx-1..2tx, 2ty-1..2ty) all have middle = ((x+1)/2,
+// (y+1)/2) = (tx, ty) (depth_image.rs:114-117 with a 1x1 group) -- so queries that share a
+// search centre sit next to each other in the pending list and ring_search_kernel can serve
+// them together.  Returns false for slots outside the image / strip.
 template <int QMODE>
-__device__ __forceinline__ void load_query(const RingArgs &a, uint32_t q, uint32_t &cx,
-                                           uint32_t &cy, uint32_t &lo, uint32_t &hi)
+__device__ __forceinline__ bool load_query(const RingArgs &a, uint32_t slot, uint32_t &q,
+                                           uint32_t &cx, uint32_t &cy, uint32_t &lo,
+                                           uint32_t &hi)
 {
     if constexpr (QMODE == 0) {
-        const uint32_t x = q % a.w, y = a.row0 + q / a.w;
+        const uint32_t tile = slot >> 2, m = slot & 3u;
+        const uint32_t tx = tile % a.ntx, ty = a.ty0 + tile / a.ntx;
+        const uint32_t x = 2u * tx - 1u + (m & 1u), y = 2u * ty - 1u + (m >> 1); // may wrap
+        if (slot >= a.n_slots || x >= a.w || y < a.row0 || y >= a.row1)
+            return false;
+        q = (y - a.row0) * a.w + x;
         const uint8_t *p = a.main_px + (size_t)y * a.mstride + (size_t)x * a.mch;
         const uint8_t v[3] = {p[0], p[1], p[2]};
-        cx = (x + 1u) >> 1; // (x + 1)/2, (y + 1)/2 for a 1x1 group, depth_image.rs:114-117
-        cy = (y + 1u) >> 1;
+        cx = tx;
+        cy = ty;
         make_box(v, a.prec, lo, hi);
+        return true;
     } else {
-        const Query qq = a.queries[q];
+        if (slot >= a.n)
+            return false;
+        q = slot;
+        const Query qq = a.queries[slot];
         cx = qq.cx;
         cy = qq.cy;
         lo = qq.lo;
         hi = qq.hi;
+        return true;
     }
 }
 
@@ -366,15 +384,15 @@ __global__ __launch_bounds__(256) void ring0_kernel(RingArgs a)
     __shared__ uint32_t s_base;
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     Query rec[kRing0Iters];
+    uint32_t qid[kRing0Iters];
     uint32_t pend_bits = 0, n_mine = 0;
     unsigned long long n_hit = 0, n_inb = 0;
 #pragma unroll
     for (uint32_t it = 0; it < kRing0Iters; ++it) {
-        const uint32_t q = (blockIdx.x * kRing0Iters + it) * 256u + threadIdx.x;
-        const bool valid = q < a.n;
-        uint32_t cx = ~0u, cy = ~0u, lo = 0, hi = 0;
-        if (valid)
-            load_query<QMODE>(a, q, cx, cy, lo, hi);
+        const uint32_t slot = (blockIdx.x * kRing0Iters + it) * 256u + threadIdx.x;
+        uint32_t q = 0, cx = ~0u, cy = ~0u, lo = 0, hi = 0;
+        const bool valid = load_query<QMODE>(a, slot, q, cx, cy, lo, hi);
+        qid[it] = q;
         const bool inb = valid && cx < a.wa && cy < a.ha && a.max_steps > 0;
         bool fnd = false, pending = false;
         if (inb) {
@@ -421,7 +439,7 @@ __global__ __launch_bounds__(256) void ring0_kernel(RingArgs a)
         const unsigned long long pm = __ballot(pending);
         if (pending) {
             const uint32_t at = slot + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull));
-            a.pending[at] = (blockIdx.x * kRing0Iters + it) * 256u + threadIdx.x;
+            a.pending[at] = qid[it];
             a.pending_rec[at] = rec[it];
         }
         slot += (uint32_t)__popcll(pm);
@@ -503,9 +521,20 @@ __global__ __launch_bounds__(256) STEPTH_SEARCH_ATTR void ring_search_kernel(Sea
             rec = a.rec[run0 + lane];
         uint32_t result = kNoKey; // lane i: best key of record run0 + i
 
-        for (uint32_t r = 0; r < run_len; ++r) {
+        // Records with the same search centre (the 2x2 pixel tiles of the 1x1 mode put up to
+        // four of them side by side) are served together: one set of block tests and one read
+        // of every probed block for all their colour boxes.
+        unsigned long long starts;
+        {
+            const uint32_t pcx = (uint32_t)__shfl_up((int)rec.cx, 1, 64);
+            const uint32_t pcy = (uint32_t)__shfl_up((int)rec.cy, 1, 64);
+            starts = ballot(lane < run_len && (FAR || lane == 0 || rec.cx != pcx || rec.cy != pcy));
+        }
+        for (uint32_t r = 0; r < run_len;) {
+            const unsigned long long later = (starts >> r) >> 1; // group starts after r
+            const uint32_t till = later ? (uint32_t)__ffsll(later) : run_len - r;
+            const uint32_t M = min(min(till, run_len - r), 4u); // members r .. r+M-1
             const uint32_t qx = bcast(rec.cx, (int)r), qy = bcast(rec.cy, (int)r);
-            const uint32_t qlo = bcast(rec.lo, (int)r), qhi = bcast(rec.hi, (int)r);
             const uint32_t smax = max(max(qx, a.wa - 1u - qx), max(qy, a.ha - 1u - qy));
             const uint32_t s_end = min(a.max_steps, smax + 1u); // rings 0..s_end-1 are searched
             const int cbx = (int)(qx >> kBlkShift), cby = (int)(qy >> kBlkShift);
@@ -513,21 +542,63 @@ __global__ __launch_bounds__(256) STEPTH_SEARCH_ATTR void ring_search_kernel(Sea
             // lane's cell offset from the centre inside block (0,0)
             const int rx = lx + nox, ry = ly + noy;
 
-            uint32_t best = kNoKey; // wave-uniform best key so far
-            uint32_t limit = s_end; // a block whose nearest cell is at ring >= limit is useless
+            // per member: colour box, best key so far, and `limit`: a block whose nearest cell
+            // is at ring >= limit is useless to it (0 = member settled / absent)
+            uint32_t qlo[4], qhi[4], best[4], limit[4];
+#pragma unroll
+            for (uint32_t m = 0; m < 4; ++m) {
+                const int src = (int)min(r + m, run_len - 1u);
+                qlo[m] = bcast(rec.lo, src);
+                qhi[m] = bcast(rec.hi, src);
+                best[m] = kNoKey;
+                limit[m] = m < M ? s_end : 0u;
+            }
+            uint32_t glimit = s_end; // max of the members' limits
 
-            // One step of cell probes per surviving block (two in flight): 64 lanes read its
-            // 64 cells (256 contiguous bytes), test them and, only if some cell matched,
-            // compute keys.  `bi,bj,dmin` are per lane (lane = block of the current step).
-            auto probe = [&](int sbi, int sbj, uint32_t c, uint32_t &mine) {
-                const bool hit = cell_in_box(c, qlo, qhi);
-                if (ballot(hit)) {
-                    uint32_t ring;
-                    const uint32_t key = scan_key(sbi * 8 + rx, sbj * 8 + ry, a.pos_bits, ring);
-                    if (hit && ring < s_end)
-                        mine = min(mine, key);
-                }
+            // box [lo,hi] meets [bmin,bmax] on every channel
+            auto meets = [&](uint2 bb, uint32_t lo, uint32_t hi) {
+                return (((bb.x - lo) & (hi - bb.y)) | ~kGuard) == 0xFFFFFFFFu;
             };
+            // some member that can still use a block at distance `d` has a box meeting `bb`
+            auto wanted = [&](uint2 bb, uint32_t d) {
+                bool w = false;
+#pragma unroll
+                for (uint32_t m = 0; m < 4; ++m)
+                    w |= d < limit[m] && meets(bb, qlo[m], qhi[m]);
+                return w;
+            };
+            // smallest ring of any cell of block (bi,bj): max over axes of max(8b-o, o-8b-7, 0)
+            auto block_dmin = [&](int bi, int bj) {
+                const int ax = (bi << 3) + nox, ay = (bj << 3) + noy;
+                return (uint32_t)max(max(max(ax, -7 - ax), max(ay, -7 - ay)), 0);
+            };
+            // all lanes hold cell `c` of block (sbi,sbj) whose nearest cell is at ring `d`:
+            // test it for every member the block can still help; keys only on a hit
+            auto resolve = [&](int sbi, int sbj, uint32_t d, uint32_t c) -> bool {
+                bool hit[4], any = false;
+#pragma unroll
+                for (uint32_t m = 0; m < 4; ++m) {
+                    hit[m] = d < limit[m] && cell_in_box(c, qlo[m], qhi[m]);
+                    any |= hit[m];
+                }
+                if (!ballot(any))
+                    return false;
+                uint32_t ring;
+                const uint32_t key = scan_key(sbi * 8 + rx, sbj * 8 + ry, a.pos_bits, ring);
+                bool changed = false;
+#pragma unroll
+                for (uint32_t m = 0; m < 4; ++m) {
+                    const uint32_t mine = (hit[m] && ring < s_end) ? key : kNoKey;
+                    if (ballot(mine != kNoKey)) {
+                        best[m] = min(best[m], wave_min_dpp(mine));
+                        limit[m] = min(limit[m], (best[m] >> ring_shift) + 1u);
+                        changed = true;
+                    }
+                }
+                return changed;
+            };
+            // One step of cell probes per surviving block (two in flight): 64 lanes read its
+            // 64 cells (256 contiguous bytes).  `bi,bj,dmin` are per lane (lane = block).
             auto probe_blocks = [&](unsigned long long pm, int bi, int bj, uint32_t dmin) {
                 while (pm) {
                     const int b0 = __ffsll(pm) - 1;
@@ -537,35 +608,25 @@ __global__ __launch_bounds__(256) STEPTH_SEARCH_ATTR void ring_search_kernel(Sea
                     pm &= pm - 1; // no-op when pm == 0
                     const int i0 = (int)bcast((uint32_t)bi, b0), j0 = (int)bcast((uint32_t)bj, b0);
                     const int i1 = (int)bcast((uint32_t)bi, b1), j1 = (int)bcast((uint32_t)bj, b1);
+                    const uint32_t d0 = bcast(dmin, b0), d1 = bcast(dmin, b1);
                     const uint32_t blk0 = (uint32_t)(cby + j0) * a.bw + (uint32_t)(cbx + i0);
                     const uint32_t blk1 = (uint32_t)(cby + j1) * a.bw + (uint32_t)(cbx + i1);
                     const uint32_t c0 = a.T[blk0 * 64u + lane];
                     const uint32_t c1 = a.T[blk1 * 64u + lane];
-                    uint32_t mine = kNoKey;
-                    probe(i0, j0, c0, mine);
+                    bool changed = resolve(i0, j0, d0, c0);
                     if (two)
-                        probe(i1, j1, c1, mine);
+                        changed |= resolve(i1, j1, d1, c1);
                     if constexpr (STATS) {
                         n_probe += two ? 128ull : 64ull;
                         n_blocks += two ? 2ull : 1ull;
                     }
-                    if (ballot(mine != kNoKey)) {
-                        // a match: everything farther than its ring is now useless,
+                    if (changed) {
+                        // everything farther than every member's best ring is now useless,
                         // including the rest of this step's survivors
-                        best = min(best, wave_min_dpp(mine));
-                        limit = min(limit, (best >> ring_shift) + 1u);
-                        pm &= ballot(dmin < limit);
+                        glimit = max(max(limit[0], limit[1]), max(limit[2], limit[3]));
+                        pm &= ballot(dmin < glimit);
                     }
                 }
-            };
-            // smallest ring of any cell of block (bi,bj): max over axes of max(8b-o, o-8b-7, 0)
-            auto block_dmin = [&](int bi, int bj) {
-                const int ax = (bi << 3) + nox, ay = (bj << 3) + noy;
-                return (uint32_t)max(max(max(ax, -7 - ax), max(ay, -7 - ay)), 0);
-            };
-            // box [lo,hi] meets [bmin,bmax] on every channel
-            auto bounds_meet = [&](uint2 bb) {
-                return (((bb.x - qlo) & (qhi - bb.y)) | ~kGuard) == 0xFFFFFFFFu;
             };
 
             if constexpr (FAR) {
@@ -577,15 +638,17 @@ __global__ __launch_bounds__(256) STEPTH_SEARCH_ATTR void ring_search_kernel(Sea
                     const int bx = cbx + bi, by = cby + bj;
                     const uint32_t dmin = block_dmin(bi, bj);
                     bool cand = u0 + lane < u_end && (uint32_t)bx < a.bw &&
-                                (uint32_t)by < a.bh && dmin < limit;
+                                (uint32_t)by < a.bh && dmin < glimit;
                     if (cand)
-                        cand = bounds_meet(a.BB[(uint32_t)by * a.bw + (uint32_t)bx]);
-                    if constexpr (STATS)
+                        cand = wanted(a.BB[(uint32_t)by * a.bw + (uint32_t)bx], dmin);
+                    if constexpr (STATS) {
                         n_probe += 64ull;
+                        ++n_near;
+                    }
                     probe_blocks(ballot(cand), bi, bj, dmin);
                     // block-rings 0..m_done are complete: every cell of rings <= 8 m_done has
                     // been seen or excluded
-                    if (best != kNoKey && (best >> ring_shift) <= 8u * a.spiral_done[k])
+                    if (best[0] != kNoKey && (best[0] >> ring_shift) <= 8u * a.spiral_done[k])
                         break;
                 }
             } else {
@@ -593,21 +656,26 @@ __global__ __launch_bounds__(256) STEPTH_SEARCH_ATTR void ring_search_kernel(Sea
                 {
                     const int bx = cbx + nbi, by = cby + nbj;
                     const uint32_t dmin = block_dmin(nbi, nbj);
-                    bool cand = (uint32_t)bx < a.bw && (uint32_t)by < a.bh && dmin < limit;
+                    bool cand = (uint32_t)bx < a.bw && (uint32_t)by < a.bh && dmin < glimit;
                     if (cand)
-                        cand = bounds_meet(a.BB[(uint32_t)by * a.bw + (uint32_t)bx]);
+                        cand = wanted(a.BB[(uint32_t)by * a.bw + (uint32_t)bx], dmin);
                     if constexpr (STATS) {
                         n_probe += 64ull;
                         ++n_near;
                     }
                     probe_blocks(ballot(cand), nbi, nbj, dmin);
                 }
-                // rings <= 24 are settled; anything farther needs the far phase
-                if (s_end > 25u && !(best != kNoKey && (best >> ring_shift) <= 24u)) {
+                // a member whose best ring is <= 24 is settled; the others need the far phase
+#pragma unroll
+                for (uint32_t m = 0; m < 4; ++m)
+                    if (s_end <= 25u || (best[m] != kNoKey && (best[m] >> ring_shift) <= 24u))
+                        limit[m] = 0u;
+                glimit = max(max(limit[0], limit[1]), max(limit[2], limit[3]));
+                if (glimit) {
                     // ---- far: survey the 64x64-cell superblocks overlapping the window of
-                    // radius limit-1 -- only those whose bounds meet the box can hold a match
+                    // radius glimit-1 -- only those whose bounds meet a box can hold a match
                     // -- then one step per surviving superblock, nearest first: its 64 blocks.
-                    const int rad = (int)limit - 1;
+                    const int rad = (int)glimit - 1;
                     const int sx0 = max((int)qx - rad, 0) >> 6, sy0 = max((int)qy - rad, 0) >> 6;
                     const int sx1 = min((int)qx + rad, (int)a.wa - 1) >> 6;
                     const int sy1 = min((int)qy + rad, (int)a.ha - 1) >> 6;
@@ -622,7 +690,8 @@ __global__ __launch_bounds__(256) STEPTH_SEARCH_ATTR void ring_search_kernel(Sea
                             const int ax = (sx << 6) - (int)qx, ay = (sy << 6) - (int)qy;
                             const uint32_t dS =
                                 (uint32_t)max(max(max(ax, -63 - ax), max(ay, -63 - ay)), 0);
-                            if (dS < limit && bounds_meet(a.SB[(uint32_t)sy * a.sbw + (uint32_t)sx]))
+                            if (dS < glimit &&
+                                wanted(a.SB[(uint32_t)sy * a.sbw + (uint32_t)sx], dS))
                                 skey[h] = (dS << 8) | (uint32_t)(ty * 16 + tx);
                         }
                         if (4 * (h + 1) >= nsy)
@@ -633,9 +702,9 @@ __global__ __launch_bounds__(256) STEPTH_SEARCH_ATTR void ring_search_kernel(Sea
                         ++n_survey;
                     }
                     for (;;) {
-                        // nearest surviving superblock that can still improve the best key
+                        // nearest surviving superblock that can still improve some best key
                         uint32_t k = min(min(skey[0], skey[1]), skey[2]);
-                        k = (k >> 8) < limit ? k : kNoKey;
+                        k = (k >> 8) < glimit ? k : kNoKey;
                         if (ballot(k != kNoKey) == 0)
                             break;
                         const uint32_t pick = wave_min_dpp(k);
@@ -647,10 +716,10 @@ __global__ __launch_bounds__(256) STEPTH_SEARCH_ATTR void ring_search_kernel(Sea
                         const int bx = sx * 8 + lx, by = sy * 8 + ly;
                         const int bi = bx - cbx, bj = by - cby;
                         const uint32_t dmin = block_dmin(bi, bj);
-                        bool cand = (uint32_t)bx < a.bw && (uint32_t)by < a.bh && dmin < limit &&
+                        bool cand = (uint32_t)bx < a.bw && (uint32_t)by < a.bh && dmin < glimit &&
                                     max(abs(bi), abs(bj)) > 3;
                         if (cand)
-                            cand = bounds_meet(a.BB[(uint32_t)by * a.bw + (uint32_t)bx]);
+                            cand = wanted(a.BB[(uint32_t)by * a.bw + (uint32_t)bx], dmin);
                         if constexpr (STATS) {
                             n_probe += 64ull;
                             ++n_super;
@@ -659,8 +728,11 @@ __global__ __launch_bounds__(256) STEPTH_SEARCH_ATTR void ring_search_kernel(Sea
                     }
                 }
             }
-            if (lane == r)
-                result = best;
+#pragma unroll
+            for (uint32_t m = 0; m < 4; ++m)
+                if (m < M && lane == r + m)
+                    result = best[m];
+            r += M;
         }
         if (lane < run_len)
             a.key[run0 + lane] = result;
