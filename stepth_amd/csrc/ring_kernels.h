@@ -253,7 +253,7 @@ struct RingArgs {
 
 constexpr uint32_t kNoKey = 0xFFFFFFFFu;
 #ifndef STEPTH_RUN
-#define STEPTH_RUN 8
+#define STEPTH_RUN 12
 #endif
 // <= 80 SGPRs keeps 8 workgroups of 256 threads resident per CU (MI355X_MICROARCH.md,
 // "Residency"); the kernel wants ~100 without the cap
