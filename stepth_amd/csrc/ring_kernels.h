@@ -481,6 +481,7 @@ __global__ __launch_bounds__(256) STEPTH_SEARCH_ATTR void ring_search_kernel(Sea
 {
     const uint32_t lane = threadIdx.x & 63u;
     const int lx = (int)(lane & 7u), ly = (int)(lane >> 3);
+    const uint32_t lane_t = ((lane & 7u) << 3) | (lane >> 3); // transposed cell index
     const uint32_t ring_shift = a.pos_bits + 2u;
     const uint32_t count = *a.count;
     unsigned long long n_probe = 0, n_near = 0, n_survey = 0, n_super = 0, n_blocks = 0;
@@ -539,8 +540,6 @@ __global__ __launch_bounds__(256) STEPTH_SEARCH_ATTR void ring_search_kernel(Sea
             const uint32_t s_end = min(a.max_steps, smax + 1u); // rings 0..s_end-1 are searched
             const int cbx = (int)(qx >> kBlkShift), cby = (int)(qy >> kBlkShift);
             const int nox = -(int)(qx & 7u), noy = -(int)(qy & 7u);
-            // lane's cell offset from the centre inside block (0,0)
-            const int rx = lx + nox, ry = ly + noy;
 
             // per member: colour box, best key so far, and `limit`: a block whose nearest cell
             // is at ring >= limit is useless to it (0 = member settled / absent)
@@ -572,9 +571,34 @@ __global__ __launch_bounds__(256) STEPTH_SEARCH_ATTR void ring_search_kernel(Sea
                 const int ax = (bi << 3) + nox, ay = (bj << 3) + noy;
                 return (uint32_t)max(max(max(ax, -7 - ax), max(ay, -7 - ay)), 0);
             };
-            // all lanes hold cell `c` of block (sbi,sbj) whose nearest cell is at ring `d`:
-            // test it for every member the block can still help; keys only on a hit
-            auto resolve = [&](int sbi, int sbj, uint32_t d, uint32_t c) -> bool {
+            // Most blocks lie entirely inside ONE side region of the reference's scan (all
+            // their cells on "row y+s" sides, or all on "row y-s", "column x+s", "column x-s"
+            // sides).  There the scan order inside the block is: nearest line first, then
+            // ascending along the line -- so if the lanes read the cells in that order (rows
+            // or columns, forwards or backwards: `cell_of`), a member's smallest key sits in
+            // the lowest hit lane and no wave-min is needed.  Blocks on the diagonals (type 4)
+            // keep the natural order and pay for the reduction.
+            // info = bi (14 bits) | bj (14 bits) | type << 28, per lane (lane = block)
+            auto block_info = [&](int bi, int bj) {
+                const int x0 = (bi << 3) + nox, y0 = (bj << 3) + noy; // offsets of cell (0,0)
+                const int x1 = x0 + 7, y1 = y0 + 7;
+                const int mx = max(-x0, x1), my = max(-y0, y1);       // max |dx|, max |dy|
+                const uint32_t type = (y0 > 0 && y0 >= mx)    ? 0u   // rows below:    side 0
+                                      : (y1 < 0 && -y1 >= mx) ? 1u   // rows above:    side 1
+                                      : (x0 > 0 && x0 > my)   ? 2u   // columns right: side 2
+                                      : (x1 < 0 && -x1 > my)  ? 3u   // columns left:  side 3
+                                                              : 4u;
+                return ((uint32_t)bi & 0x3fffu) | (((uint32_t)bj & 0x3fffu) << 14) | (type << 28);
+            };
+            // cell (row-major index in the block) read by this lane for a block of `type`
+            auto cell_of = [&](uint32_t type) {
+                const uint32_t base = (type == 2u || type == 3u) ? lane_t : lane;
+                return base ^ (type == 1u ? 56u : type == 3u ? 7u : 0u);
+            };
+            // all lanes hold cell `cell` of block (sbi,sbj) (type, nearest ring d): test it for
+            // every member the block can still help; keys only on a hit
+            auto resolve = [&](int sbi, int sbj, uint32_t type, uint32_t d, uint32_t cell,
+                               uint32_t c) -> bool {
                 bool hit[4], any = false;
 #pragma unroll
                 for (uint32_t m = 0; m < 4; ++m) {
@@ -584,13 +608,16 @@ __global__ __launch_bounds__(256) STEPTH_SEARCH_ATTR void ring_search_kernel(Sea
                 if (!ballot(any))
                     return false;
                 uint32_t ring;
-                const uint32_t key = scan_key(sbi * 8 + rx, sbj * 8 + ry, a.pos_bits, ring);
+                const uint32_t key = scan_key(sbi * 8 + (int)(cell & 7u) + nox,
+                                              sbj * 8 + (int)(cell >> 3) + noy, a.pos_bits, ring);
                 bool changed = false;
 #pragma unroll
                 for (uint32_t m = 0; m < 4; ++m) {
-                    const uint32_t mine = (hit[m] && ring < s_end) ? key : kNoKey;
-                    if (ballot(mine != kNoKey)) {
-                        best[m] = min(best[m], wave_min_dpp(mine));
+                    const unsigned long long hm = ballot(hit[m] && ring < s_end);
+                    if (hm) {
+                        const uint32_t k = type < 4u ? bcast(key, __ffsll(hm) - 1)
+                                                     : wave_min_dpp(hit[m] && ring < s_end ? key : kNoKey);
+                        best[m] = min(best[m], k);
                         limit[m] = min(limit[m], (best[m] >> ring_shift) + 1u);
                         changed = true;
                     }
@@ -598,24 +625,27 @@ __global__ __launch_bounds__(256) STEPTH_SEARCH_ATTR void ring_search_kernel(Sea
                 return changed;
             };
             // One step of cell probes per surviving block (two in flight): 64 lanes read its
-            // 64 cells (256 contiguous bytes).  `bi,bj,dmin` are per lane (lane = block).
-            auto probe_blocks = [&](unsigned long long pm, int bi, int bj, uint32_t dmin) {
+            // 64 cells (256 contiguous bytes).  `info,dmin` are per lane (lane = block).
+            auto probe_blocks = [&](unsigned long long pm, uint32_t info, uint32_t dmin) {
                 while (pm) {
                     const int b0 = __ffsll(pm) - 1;
                     pm &= pm - 1;
                     const bool two = pm != 0;
                     const int b1 = two ? __ffsll(pm) - 1 : b0;
                     pm &= pm - 1; // no-op when pm == 0
-                    const int i0 = (int)bcast((uint32_t)bi, b0), j0 = (int)bcast((uint32_t)bj, b0);
-                    const int i1 = (int)bcast((uint32_t)bi, b1), j1 = (int)bcast((uint32_t)bj, b1);
+                    const uint32_t n0 = bcast(info, b0), n1 = bcast(info, b1);
+                    const int i0 = (int)(n0 << 18) >> 18, j0 = (int)(n0 << 4) >> 18;
+                    const int i1 = (int)(n1 << 18) >> 18, j1 = (int)(n1 << 4) >> 18;
+                    const uint32_t t0 = n0 >> 28, t1 = n1 >> 28;
                     const uint32_t d0 = bcast(dmin, b0), d1 = bcast(dmin, b1);
                     const uint32_t blk0 = (uint32_t)(cby + j0) * a.bw + (uint32_t)(cbx + i0);
                     const uint32_t blk1 = (uint32_t)(cby + j1) * a.bw + (uint32_t)(cbx + i1);
-                    const uint32_t c0 = a.T[blk0 * 64u + lane];
-                    const uint32_t c1 = a.T[blk1 * 64u + lane];
-                    bool changed = resolve(i0, j0, d0, c0);
+                    const uint32_t cell0 = cell_of(t0), cell1 = cell_of(t1);
+                    const uint32_t c0 = a.T[blk0 * 64u + cell0];
+                    const uint32_t c1 = a.T[blk1 * 64u + cell1];
+                    bool changed = resolve(i0, j0, t0, d0, cell0, c0);
                     if (two)
-                        changed |= resolve(i1, j1, d1, c1);
+                        changed |= resolve(i1, j1, t1, d1, cell1, c1);
                     if constexpr (STATS) {
                         n_probe += two ? 128ull : 64ull;
                         n_blocks += two ? 2ull : 1ull;
@@ -645,7 +675,7 @@ __global__ __launch_bounds__(256) STEPTH_SEARCH_ATTR void ring_search_kernel(Sea
                         n_probe += 64ull;
                         ++n_near;
                     }
-                    probe_blocks(ballot(cand), bi, bj, dmin);
+                    probe_blocks(ballot(cand), block_info(bi, bj), dmin);
                     // block-rings 0..m_done are complete: every cell of rings <= 8 m_done has
                     // been seen or excluded
                     if (best[0] != kNoKey && (best[0] >> ring_shift) <= 8u * a.spiral_done[k])
@@ -663,7 +693,7 @@ __global__ __launch_bounds__(256) STEPTH_SEARCH_ATTR void ring_search_kernel(Sea
                         n_probe += 64ull;
                         ++n_near;
                     }
-                    probe_blocks(ballot(cand), nbi, nbj, dmin);
+                    probe_blocks(ballot(cand), block_info(nbi, nbj), dmin);
                 }
                 // a member whose best ring is <= 24 is settled; the others need the far phase
 #pragma unroll
@@ -724,7 +754,7 @@ __global__ __launch_bounds__(256) STEPTH_SEARCH_ATTR void ring_search_kernel(Sea
                             n_probe += 64ull;
                             ++n_super;
                         }
-                        probe_blocks(ballot(cand), bi, bj, dmin);
+                        probe_blocks(ballot(cand), block_info(bi, bj), dmin);
                     }
                 }
             }
