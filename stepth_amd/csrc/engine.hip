@@ -178,7 +178,8 @@ struct KernelTimer { // brackets the dominant kernel with events when timing is 
 
 // RGB8 additional image -> tiled cells T + block bounds BB (src/depth_image.rs:96-100)
 int pack_additional(stepth_engine *e, const uint8_t *d_add, size_t stride, uint32_t wa,
-                    uint32_t ha, uint32_t &bw, uint32_t &bh)
+                    uint32_t ha, uint32_t &bw, uint32_t &bh, uint32_t row_lo = 0,
+                    uint32_t row_hi = 0xFFFFFFFFu)
 {
     bw = (wa + 7u) / 8u;
     bh = (ha + 7u) / 8u;
@@ -187,13 +188,19 @@ int pack_additional(stepth_engine *e, const uint8_t *d_add, size_t stride, uint3
         return fail(e, STEPTH_ERR_BAD_ARG, "additional image %ux%u exceeds 2^30 cells", wa, ha);
     TRY(reserve(e, e->T, nblk * 64 * 4));
     TRY(reserve(e, e->BB, nblk * 8));
-    PackArgs pa{d_add, stride, wa, ha, bw, bh, (uint32_t *)e->T.p, (uint2 *)e->BB.p};
-    hipLaunchKernelGGL(pack_additional_kernel, dim3((uint32_t)((nblk + 3) / 4)), dim3(256), 0,
+    // only the cell rows [row_lo,row_hi) can be reached by the searches of this call
+    row_hi = std::min(row_hi, ha);
+    row_lo = std::min(row_lo, row_hi);
+    const uint32_t by0 = row_lo / 8u, by1 = std::max((row_hi + 7u) / 8u, by0 + 1u);
+    PackArgs pa{d_add, stride, wa, ha, bw, bh, (uint32_t *)e->T.p, (uint2 *)e->BB.p, by0,
+                std::min(by1, bh) - by0};
+    hipLaunchKernelGGL(pack_additional_kernel, dim3((bw * pa.nby + 3u) / 4u), dim3(256), 0,
                        e->stream, pa);
     const uint32_t sbw = (bw + 7u) / 8u, sbh = (bh + 7u) / 8u;
     TRY(reserve(e, e->SB, (size_t)sbw * sbh * 8));
-    SuperArgs sa{(const uint2 *)e->BB.p, bw, bh, sbw, sbh, (uint2 *)e->SB.p};
-    hipLaunchKernelGGL(pack_super_kernel, dim3((sbw * sbh + 3u) / 4u), dim3(256), 0, e->stream, sa);
+    SuperArgs sa{(const uint2 *)e->BB.p, bw, bh, sbw, sbh, (uint2 *)e->SB.p, by0 / 8u,
+                 (by0 + pa.nby + 7u) / 8u - by0 / 8u, by0, by0 + pa.nby};
+    hipLaunchKernelGGL(pack_super_kernel, dim3((sbw * sa.nsby + 3u) / 4u), dim3(256), 0, e->stream, sa);
     HIP_TRY(e, hipGetLastError());
     return STEPTH_OK;
 }
@@ -593,7 +600,19 @@ int stepth_depth_from_additional(stepth_engine *e, const stepth_image *main_im,
         }
     } else if (p.mode == STEPTH_MODE_RING_FIRST_HIT) {
         uint32_t bw = 0, bh = 0;
-        TRY(pack_additional(e, d_add, as, add_im->width, add_im->height, bw, bh));
+        {
+            // rows of the additional image the strip's searches can reach: the centres of
+            // uniform tiles lie in rows [row0/2, (row1+tile_h)/2], every search stays within
+            // max_steps-1 rings of its centre (group lists: unknown centres, pack everything)
+            uint32_t lo = 0, hi = 0xFFFFFFFFu;
+            if (!groups && p.tile_h && p.max_steps < 0x40000000u) {
+                const uint32_t reach = p.max_steps ? p.max_steps - 1u : 0u;
+                const uint32_t c_lo = row0 / 2u, c_hi = (row1 + p.tile_h) / 2u;
+                lo = c_lo > reach ? c_lo - reach : 0u;
+                hi = c_hi + reach + 1u;
+            }
+            TRY(pack_additional(e, d_add, as, add_im->width, add_im->height, bw, bh, lo, hi));
+        }
 
         RingArgs ra{};
         ra.T = (const uint32_t *)e->T.p;

@@ -33,6 +33,7 @@ struct PackArgs {
     uint32_t bw, bh;
     uint32_t *T;
     uint2 *BB;
+    uint32_t by0, nby; // block rows to pack (a row strip only reaches part of the image)
 };
 
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
@@ -54,10 +55,11 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
 __global__ __launch_bounds__(256) void pack_additional_kernel(PackArgs a)
 {
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t blk = blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (blk >= a.bw * a.bh)
+    const uint32_t idx = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (idx >= a.bw * a.nby)
         return;
-    const uint32_t bx = blk % a.bw, by = blk / a.bw;
+    const uint32_t bx = idx % a.bw, by = a.by0 + idx / a.bw;
+    const uint32_t blk = by * a.bw + bx;
     const uint32_t x = bx * kBlk + (lane & 7u), y = by * kBlk + (lane >> 3);
     uint32_t cell = kNoCell;
     uint32_t mn[3] = {255u, 255u, 255u}, mx[3] = {0u, 0u, 0u};
@@ -83,17 +85,20 @@ struct SuperArgs {
     const uint2 *BB;
     uint32_t bw, bh, sbw, sbh;
     uint2 *SB;
+    uint32_t sby0, nsby; // superblock rows to fold, and the block rows that are valid: blocks
+    uint32_t by0, by1;   // outside [by0,by1) hold stale bounds and are left out
 };
 
 __global__ __launch_bounds__(256) void pack_super_kernel(SuperArgs a)
 {
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t sb = blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (sb >= a.sbw * a.sbh)
+    const uint32_t idx = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (idx >= a.sbw * a.nsby)
         return;
+    const uint32_t sb = (a.sby0 + idx / a.sbw) * a.sbw + idx % a.sbw;
     const uint32_t bx = (sb % a.sbw) * 8u + (lane & 7u), by = (sb / a.sbw) * 8u + (lane >> 3);
     uint32_t mn[3] = {255u, 255u, 255u}, mx[3] = {0u, 0u, 0u};
-    if (bx < a.bw && by < a.bh) {
+    if (bx < a.bw && by >= a.by0 && by < a.by1) {
         const uint2 bb = a.BB[(size_t)by * a.bw + bx];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {

@@ -306,6 +306,26 @@ def test_row_strips_compose_to_the_full_frame(engine, oracle):
             np.testing.assert_array_equal(out, ref["depth"])
 
 
+def test_strips_with_short_reach_pack_only_part_of_the_additional_image(engine, oracle, asset):
+    """a strip only packs the rows its searches can reach (centre rows +- (max_steps-1)); stale
+    rows from earlier calls with other images must never leak into the result"""
+    from stepth_amd import synth
+    from stepth_amd.sharding import strip_bounds
+    main, add = asset["main"], asset["additional"]
+    other, _, _ = synth.stereo_pair(600, 400, 32, seed=99)
+    for ms, tile in ((16, (1, 1)), (40, (1, 1)), (9, (4, 4)), (2, (1, 1))):
+        ref = oracle.depth_from_additional(main, add, P36, ms, tile)
+        engine.depth_from_additional(main, other, P36, max_steps=255)  # poison T/BB/SB
+        out = np.zeros((400, 600), np.uint8)
+        maxes = []
+        for (r0, r1) in strip_bounds(400, 8, tile[1]):
+            _, mx = engine.depth_from_additional(main, add, P36, max_steps=ms, tile=tile,
+                                                 rows=(r0, r1), raw_only=True, out=out)
+            maxes.append(mx)
+        np.testing.assert_array_equal(out, ref["raw"])
+        assert max(maxes) == ref["max"]
+
+
 def test_device_memory_async_path(engine, oracle):
     import torch
     from stepth_amd import synth
