@@ -1,0 +1,236 @@
+// stepth_depth_image.hpp -- C++ host-side mirror of the reference's `DepthImage` for the
+// open_depth_from_additional path, on top of the C-ABI (stepth_amd.h / libstepth_amd.so).
+//
+// Mirrors /root/reference/src/depth_image.rs:6-160: same method names, argument meaning and
+// error behaviour.  Rust's `Result<(), io::Error>` (ErrorKind::InvalidInput with a fixed
+// message) becomes `stepth::Result`: ok() or the message "Failed to open image" /
+// "Sizes don't match".  All compute of the path runs in the HIP engine; this header only
+// holds the buffers and reads/writes binary PNM files (P6 = RGB8, P5 = Luma8) -- no JPEG/PNG
+// decoder is linked here, other formats fail with "Failed to open image" exactly like an
+// unreadable file does in the reference (src/depth_image.rs:13-17).
+//
+// Post-processing consumers of a finished depth map (highlight_depth, depth_split,
+// select_foreground, slice, resize) and MaskImage are outside the path and not mirrored.
+#pragma once
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "stepth_amd.h"
+
+namespace stepth {
+
+struct Result { // Ok(()) or Err(io::Error::new(InvalidInput, message))
+    std::string message;
+    bool ok() const { return message.empty(); }
+    static Result Ok() { return {}; }
+    static Result Err(const char *m) { return {m}; }
+};
+
+struct Dimensions { // disage::Dimensions
+    uint32_t width = 0, height = 0;
+};
+
+// image::ImageBuffer<Rgba<u8>|Luma<u8>, Vec<u8>>: row-major, no padding
+struct Buffer {
+    uint32_t width = 0, height = 0, channels = 0;
+    std::vector<uint8_t> data;
+};
+
+namespace detail {
+inline bool read_token(FILE *f, long &v)
+{
+    int c = fgetc(f);
+    for (;;) { // whitespace and # comments
+        while (c == ' ' || c == '\t' || c == '\n' || c == '\r')
+            c = fgetc(f);
+        if (c != '#')
+            break;
+        while (c != '\n' && c != EOF)
+            c = fgetc(f);
+    }
+    if (c < '0' || c > '9')
+        return false;
+    v = 0;
+    while (c >= '0' && c <= '9') {
+        v = v * 10 + (c - '0');
+        if (v > 1000000)
+            return false;
+        c = fgetc(f);
+    }
+    return true; // one whitespace byte after the token has been consumed
+}
+
+// binary PNM: P6 -> 3 channels, P5 -> 1 channel, maxval 255
+inline bool read_pnm(const std::string &path, Buffer &out)
+{
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f)
+        return false;
+    bool good = false;
+    char magic[2] = {0, 0};
+    long w = 0, h = 0, maxv = 0;
+    if (fread(magic, 1, 2, f) == 2 && magic[0] == 'P' && (magic[1] == '5' || magic[1] == '6') &&
+        read_token(f, w) && read_token(f, h) && read_token(f, maxv) && w > 0 && h > 0 &&
+        w <= 65535 && h <= 65535 && maxv == 255) {
+        out.width = (uint32_t)w;
+        out.height = (uint32_t)h;
+        out.channels = magic[1] == '6' ? 3u : 1u;
+        out.data.resize((size_t)w * h * out.channels);
+        good = fread(out.data.data(), 1, out.data.size(), f) == out.data.size();
+    }
+    fclose(f);
+    return good;
+}
+
+inline bool write_pnm(const std::string &path, const Buffer &b)
+{
+    if (b.channels != 1 && b.channels != 3)
+        return false;
+    FILE *f = fopen(path.c_str(), "wb");
+    if (!f)
+        return false;
+    fprintf(f, "P%c\n%u %u\n255\n", b.channels == 3 ? '6' : '5', b.width, b.height);
+    const bool good = fwrite(b.data.data(), 1, b.data.size(), f) == b.data.size();
+    return fclose(f) == 0 && good;
+}
+} // namespace detail
+
+// DynamicImage::to_rgba8 / to_rgb8 / to_luma8 for the two formats read here
+inline Buffer to_rgba8(const Buffer &s)
+{
+    Buffer d{s.width, s.height, 4, std::vector<uint8_t>((size_t)s.width * s.height * 4)};
+    for (size_t i = 0, n = (size_t)s.width * s.height; i < n; ++i) {
+        const uint8_t *p = &s.data[i * s.channels];
+        d.data[4 * i + 0] = p[0];
+        d.data[4 * i + 1] = s.channels >= 3 ? p[1] : p[0];
+        d.data[4 * i + 2] = s.channels >= 3 ? p[2] : p[0];
+        d.data[4 * i + 3] = s.channels == 4 ? p[3] : 255;
+    }
+    return d;
+}
+
+inline Buffer to_rgb8(const Buffer &s)
+{
+    Buffer d{s.width, s.height, 3, std::vector<uint8_t>((size_t)s.width * s.height * 3)};
+    for (size_t i = 0, n = (size_t)s.width * s.height; i < n; ++i) {
+        const uint8_t *p = &s.data[i * s.channels];
+        d.data[3 * i + 0] = p[0];
+        d.data[3 * i + 1] = s.channels >= 3 ? p[1] : p[0];
+        d.data[3 * i + 2] = s.channels >= 3 ? p[2] : p[0];
+    }
+    return d;
+}
+
+// what the reference hard-codes or delegates to disage (src/depth_image.rs:101-110, :119)
+struct DepthOptions {
+    uint32_t max_steps = 255;         // the literal at :119
+    uint32_t tile_w = 1, tile_h = 1;  // uniform groups when `groups` is empty
+    std::vector<stepth_group> groups; // stand-in for disage::open::rgb_discrete's output
+    bool gaussian_tail = true;        // the same-size Gaussian resample at :133-134
+};
+
+// `pub struct DepthImage { pub image: RgbaImage, pub depth: GrayImage }`, depth_image.rs:6-10
+class DepthImage {
+  public:
+    Buffer image; // Rgba8
+    Buffer depth; // Luma8
+
+    using Options = DepthOptions;
+
+    DepthImage() = default; // #[derive(Default)]
+
+    // src/depth_image.rs:12-21
+    static Result open(const std::string &image_path, DepthImage &out)
+    {
+        Buffer img;
+        if (!detail::read_pnm(image_path, img))
+            return Result::Err("Failed to open image");
+        out = from_image(img);
+        return Result::Ok();
+    }
+
+    // src/depth_image.rs:23-27
+    static DepthImage from_image(const Buffer &img)
+    {
+        DepthImage d;
+        d.image = to_rgba8(img);
+        d.depth = Buffer{img.width, img.height, 1,
+                         std::vector<uint8_t>((size_t)img.width * img.height, 0)};
+        return d;
+    }
+
+    uint32_t width() const { return image.width; }    // :138-140
+    uint32_t height() const { return image.height; }  // :142-144
+    Dimensions dimensions() const { return {width(), height()}; } // :155-160
+
+    // src/depth_image.rs:37-49
+    Result load_depth(Buffer d)
+    {
+        if (d.channels == 1 && d.width == width() && d.height == height()) {
+            depth = std::move(d);
+            return Result::Ok();
+        }
+        return Result::Err("Sizes don't match");
+    }
+
+    // src/depth_image.rs:65-74
+    Result open_depth(const std::string &depth_path)
+    {
+        Buffer d;
+        if (!detail::read_pnm(depth_path, d) || d.channels != 1)
+            return Result::Err("Failed to open image");
+        return load_depth(std::move(d));
+    }
+
+    // src/depth_image.rs:76-89
+    Result open_depth_from_additional(stepth_engine *engine, const std::string &add_path,
+                                      const uint8_t precision[3], const Options &opt = Options())
+    {
+        Buffer add;
+        if (!detail::read_pnm(add_path, add))
+            return Result::Err("Failed to open image");
+        return load_depth_from_additional(engine, add, precision, opt);
+    }
+
+    // src/depth_image.rs:91-136.  Where the reference panics on a zero maximum (:127) this
+    // returns Err("every distance is zero ...") and leaves `depth` all zero.
+    Result load_depth_from_additional(stepth_engine *engine, const Buffer &add_image,
+                                      const uint8_t precision[3], const Options &opt = Options())
+    {
+        const Buffer add = to_rgb8(add_image); // :96
+        Buffer out{width(), height(), 1, std::vector<uint8_t>((size_t)width() * height(), 0)};
+        stepth_image mi{image.data.data(), width(), height(), 4, STEPTH_MEM_HOST,
+                        (size_t)width() * 4};
+        stepth_image ai{add.data.data(), add.width, add.height, 3, STEPTH_MEM_HOST,
+                        (size_t)add.width * 3};
+        stepth_image di{out.data.data(), out.width, out.height, 1, STEPTH_MEM_HOST,
+                        (size_t)out.width};
+        stepth_params p{};
+        p.struct_size = sizeof p;
+        p.mode = STEPTH_MODE_RING_FIRST_HIT;
+        p.precision[0] = precision[0];
+        p.precision[1] = precision[1];
+        p.precision[2] = precision[2];
+        p.max_steps = opt.max_steps;
+        p.tile_w = opt.tile_w;
+        p.tile_h = opt.tile_h;
+        p.flags = opt.gaussian_tail ? STEPTH_FLAG_GAUSSIAN_TAIL : 0u;
+        uint32_t max = 0;
+        const int rc = stepth_depth_from_additional(
+            engine, &mi, &ai, &p, opt.groups.empty() ? nullptr : opt.groups.data(),
+            opt.groups.size(), STEPTH_MEM_HOST, &di, &max);
+        if (rc == STEPTH_ERR_MAX_ZERO) {
+            depth = std::move(out);
+            return Result::Err(stepth_status_string(rc));
+        }
+        if (rc != STEPTH_OK)
+            return Result::Err(rc == STEPTH_ERR_SIZE_MISMATCH ? "Sizes don't match"
+                                                              : stepth_last_error(engine));
+        return load_depth(std::move(out)); // :135
+    }
+};
+
+} // namespace stepth

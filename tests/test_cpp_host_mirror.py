@@ -1,0 +1,69 @@
+"""The C++ host mirror of the reference's DepthImage (include/stepth_depth_image.hpp) through
+its CLI (stepth_amd/stepth_depth_cli, built by __graft_entry__.build()): the README flow of
+the reference (Readme.md:11-16) with PNM files, output compared with the oracle."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+CLI = os.path.join(ROOT, "stepth_amd", "stepth_depth_cli")
+
+
+def write_pnm(path, a):
+    a = np.ascontiguousarray(a, np.uint8)
+    magic = b"P6" if a.ndim == 3 else b"P5"
+    with open(path, "wb") as f:
+        f.write(magic + b"\n# written by the test\n%d %d\n255\n" % (a.shape[1], a.shape[0]))
+        f.write(a.tobytes())
+
+
+def read_pgm(path):
+    data = open(path, "rb").read()
+    parts = data.split(b"\n", 3)
+    assert parts[0] == b"P5" and parts[2] == b"255"
+    w, h = map(int, parts[1].split())
+    return np.frombuffer(parts[3], np.uint8).reshape(h, w)
+
+
+def test_cli_is_built_and_fails_loudly_without_a_device():
+    import torch
+    assert os.path.exists(CLI), "run __graft_entry__.build()"
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    r = subprocess.run([CLI, "--check-errors"], capture_output=True, text=True)
+    assert r.returncode != 0 and "no HIP device" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cpp_mirror_error_contract():
+    r = subprocess.run([CLI, "--check-errors"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip() == "OK", r.stderr
+
+
+@pytest.mark.gpu
+def test_cpp_mirror_readme_flow_matches_oracle(oracle, asset, tmp_path):
+    write_pnm(tmp_path / "main.ppm", asset["main"])
+    write_pnm(tmp_path / "additional.ppm", asset["additional"])
+    ref = oracle.depth_from_additional(asset["main"], asset["additional"], [36] * 3)
+    out = tmp_path / "depth.pgm"
+    r = subprocess.run([CLI, str(tmp_path / "main.ppm"), str(tmp_path / "additional.ppm"),
+                        str(out)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    # default = like the reference: precision u8::MAX/7 and the Gaussian tail (:133-134)
+    np.testing.assert_array_equal(read_pgm(out), oracle.gaussian_same_size(ref["depth"]))
+    r = subprocess.run([CLI, str(tmp_path / "main.ppm"), str(tmp_path / "additional.ppm"),
+                        str(out), "36", "--no-gaussian"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    np.testing.assert_array_equal(read_pgm(out), ref["depth"])
+    ref5 = oracle.depth_from_additional(asset["main"], asset["additional"], [20] * 3, 64, (5, 5))
+    r = subprocess.run([CLI, str(tmp_path / "main.ppm"), str(tmp_path / "additional.ppm"),
+                        str(out), "20", "--no-gaussian", "--max-steps", "64", "--tile", "5", "5"],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    np.testing.assert_array_equal(read_pgm(out), ref5["depth"])
+    r = subprocess.run([CLI, str(tmp_path / "missing.ppm"), str(tmp_path / "additional.ppm"),
+                        str(out)], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "Failed to open image" in r.stderr
