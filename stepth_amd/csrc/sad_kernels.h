@@ -10,7 +10,7 @@
 // clamp-to-edge rule in (left apron rad [+ d_max-1 for R], right apron rad + 64, rad rows
 // above and below), so the search kernel never clamps an index.
 //
-// sad_search_kernel<WIN, DC>: one wave = 64 adjacent columns x kSadRows output rows.  Lane x
+// sad_search_kernel<WIN, DC, ROWS>: one wave = 64 adjacent columns x ROWS output rows.  Lane x
 // owns column x.  For a chunk of DC disparities it walks down the input rows; per row it
 // reads the WIN left cells and the DC+WIN-1 right cells its column needs (consecutive lanes
 // read consecutive dwords), forms the horizontal window sums H(d) with WIN chained v_sad_u8
@@ -71,14 +71,16 @@ __global__ __launch_bounds__(256) void sad_pack_kernel(SadPackArgs a)
     }
 }
 
-constexpr int kSadRows = 16; // output rows per wave
 constexpr int kSadPadD = 16; // extra left apron of the R plane: the last chunk of DC
                              // disparities may run past d_max (those costs are ignored)
 
-template <int WIN, int DC>
+// ROWS = output rows per wave: 16 costs (16+WIN-1)/16 input rows per output row, 8 costs more
+// but gives small frames twice the waves
+template <int WIN, int DC, int ROWS>
 __global__ __launch_bounds__(256) void sad_search_kernel(SadArgs a)
 {
     constexpr int RAD = WIN / 2;
+    constexpr int kSadRows = ROWS;
     __shared__ uint32_t s_best[4][kSadRows][64]; // running min cost
     __shared__ uint32_t s_pick[4][kSadRows][64]; // bit 31: decided (under threshold); low: d
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -272,13 +274,24 @@ inline int launch_sad_pack(const SadArgs &a, hipStream_t stream)
 inline int launch_sad(const SadArgs &a, hipStream_t stream)
 {
     if (sad_has_fast_path(a.win)) {
-        dim3 grid((a.w + 255) / 256, (a.row1 - a.row0 + kSadRows - 1) / kSadRows);
+        const uint32_t cols = (a.w + 255) / 256, rows = a.row1 - a.row0;
+        // enough waves to fill 256 CUs x 12 wave slots with 16-row strips?
+        const bool tall = (size_t)cols * 4 * ((rows + 15) / 16) >= 6144;
+        const dim3 grid(cols, tall ? (rows + 15) / 16 : (rows + 7) / 8);
+#define STEPTH_SAD_LAUNCH(W, D)                                                               \
+    do {                                                                                      \
+        if (tall)                                                                             \
+            hipLaunchKernelGGL((sad_search_kernel<W, D, 16>), grid, dim3(256), 0, stream, a); \
+        else                                                                                  \
+            hipLaunchKernelGGL((sad_search_kernel<W, D, 8>), grid, dim3(256), 0, stream, a);  \
+    } while (0)
         switch (a.win) {
-        case 3: hipLaunchKernelGGL((sad_search_kernel<3, 16>), grid, dim3(256), 0, stream, a); break;
-        case 5: hipLaunchKernelGGL((sad_search_kernel<5, 16>), grid, dim3(256), 0, stream, a); break;
-        case 7: hipLaunchKernelGGL((sad_search_kernel<7, 8>), grid, dim3(256), 0, stream, a); break;
-        default: hipLaunchKernelGGL((sad_search_kernel<9, 8>), grid, dim3(256), 0, stream, a); break;
+        case 3: STEPTH_SAD_LAUNCH(3, 16); break;
+        case 5: STEPTH_SAD_LAUNCH(5, 16); break;
+        case 7: STEPTH_SAD_LAUNCH(7, 8); break;
+        default: STEPTH_SAD_LAUNCH(9, 8); break;
         }
+#undef STEPTH_SAD_LAUNCH
         return hipGetLastError() == hipSuccess ? 0 : -3;
     }
     const int rad = (int)a.win / 2;
