@@ -232,12 +232,33 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                "kernel": "ring_search_kernel" if args.mode == "ring" else "sad_match_kernel",
+                "kernel": "ring_search_kernel" if args.mode == "ring" else "sad_search_kernel",
                 "kernel_avg_ms": round(k_avg_ms, 4), "kernel_launches": klaunches,
                 "algorithmic_bytes_per_launch": ALGO_BYTES_PER_PIXEL * px_launch,
                 "probes_per_pixel": None if probes_pp is None else round(probes_pp, 1),
             },
         }
+        if args.mode == "ring" and world == 1:
+            # the engine's second mode on the same frames (north_star's literal windowed SAD;
+            # no counterpart in the reference): a short extra leg, outside the timed region
+            sworker = EngineStripWorker(eng, prec, mode=MODE_SAD_WINDOW, d_max=args.d_max,
+                                        win=args.win)
+            sharded_depth(sworker, frames, H, W)
+            torch.cuda.synchronize()
+            eng.kernel_time_enable(True)
+            t1 = time.perf_counter()
+            for _ in range(3):
+                sharded_depth(sworker, frames, H, W)
+            torch.cuda.synchronize()
+            sdt = (time.perf_counter() - t1) / 3
+            sms, sl = eng.kernel_time_read()
+            eng.kernel_time_enable(False)
+            out["sad_mode"] = {
+                "value": round(px_step / sdt / 1e6, 3), "unit": "Mpixels/s",
+                "workload": f"windowed SAD {args.win}x{args.win}, d_max={args.d_max}, same frames",
+                "kernel": "sad_search_kernel", "kernel_avg_ms": round(sms / max(sl, 1), 4),
+                "hbm_frac": round(ALGO_BYTES_PER_PIXEL * W * H / (sms / max(sl, 1) * 1e-3) / 1e9
+                                  / HBM_PEAK_GBS, 6)}
         if not args.no_cpu_baseline:
             base, ref_depth = cpu_baseline(frames_np[0], args)
             out["cpu_baseline"] = base
