@@ -440,3 +440,58 @@ def test_full_size_properties_1080p(engine):
     for rows in ((0, 540), (540, 1080)):
         engine.depth_from_additional(l, r, P36, max_steps=128, rows=rows, raw_only=True, out=out)
     np.testing.assert_array_equal(out, raw)
+
+
+def _big_frame(w, h):
+    """a large synthetic pair assembled from mirrored 960x540 tiles (fast to generate)"""
+    from stepth_amd import synth
+    l, r, _ = synth.stereo_pair(960, 540, 128, seed=0x4B)
+    def tile(a):
+        row = np.concatenate([a, a[:, ::-1]], axis=1)
+        quad = np.concatenate([row, row[::-1]], axis=0)
+        reps = (-(-h // quad.shape[0]), -(-w // quad.shape[1]), 1)
+        return np.ascontiguousarray(np.tile(quad, reps)[:h, :w])
+    return tile(l), tile(r)
+
+
+@pytest.mark.parametrize("w,h,ms", [(3840, 2160, 128), (7680, 4320, 255)])
+def test_full_size_properties_4k_8k(engine, w, h, ms):
+    """BASELINE configs 3 and 5 (4K d_max=128, 8K d_max=256 -> max_steps 255) without the
+    oracle: determinism, normalise consistency, ring-0 pixels zero, strips (as dealt to 8
+    ranks) compose to the full frame, the search never reports a distance beyond its reach"""
+    from stepth_amd.sharding import strip_bounds
+    l, r = _big_frame(w, h)
+    raw, mx = engine.depth_from_additional(l, r, P36, max_steps=ms, raw_only=True)
+    depth, mx2 = engine.depth_from_additional(l, r, P36, max_steps=ms)
+    assert mx == mx2 == int(raw.max()) and mx > 0
+    reach = int(np.floor(np.hypot(ms - 1, ms - 1)))
+    assert mx <= min(reach, 255)
+    np.testing.assert_array_equal(depth, (raw.astype(np.uint32) * 255 // mx).astype(np.uint8))
+    ys, xs = np.mgrid[0:h, 0:w]
+    centre = r[(ys + 1) // 2, (xs + 1) // 2].astype(np.int16)
+    ring0 = (np.abs(centre - l.astype(np.int16)) < 36).all(axis=2)
+    del ys, xs, centre
+    assert not raw[ring0].any()
+    out = np.zeros_like(raw)
+    for rows in strip_bounds(h, 8):
+        engine.depth_from_additional(l, r, P36, max_steps=ms, rows=rows, raw_only=True, out=out)
+    np.testing.assert_array_equal(out, raw)
+
+
+def test_images_beyond_the_cell_index_range_are_refused(engine):
+    """kernels index cells with 32-bit byte offsets: more than 2^30 cells is a clean error"""
+    import ctypes as C
+    import torch
+    from stepth_amd import _lib as L
+    buf = torch.zeros(1 << 20, dtype=torch.uint8, device="cuda")
+    big = L.Image(buf.data_ptr(), 40000, 40000, 3, L.MEM_DEVICE, 120000)
+    small = L.Image(buf.data_ptr(), 16, 16, 3, L.MEM_DEVICE, 48)
+    depth = L.Image(buf.data_ptr(), 16, 16, 1, L.MEM_DEVICE, 16)
+    p = L.Params()
+    p.struct_size = C.sizeof(L.Params)
+    p.precision = (C.c_uint8 * 3)(36, 36, 36)
+    p.max_steps, p.tile_w, p.tile_h = 255, 1, 1
+    st = engine._lib.stepth_depth_from_additional(engine._h, C.byref(small), C.byref(big),
+                                                  C.byref(p), None, 0, 0, C.byref(depth), None)
+    assert st == L.ERR_BAD_ARG
+    assert b"2^30" in engine._lib.stepth_last_error(engine._h)
