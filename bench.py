@@ -110,6 +110,9 @@ def main():
     ap.add_argument("--precision", type=int, default=36)
     ap.add_argument("--frames-per-gpu", dest="fpg", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--interleave", type=int, default=8,
+                    help="N > 1, ring mode: deal rows in interleaved blocks of this many rows "
+                         "(0 = contiguous strips); balances the data-dependent work")
     ap.add_argument("--backend", default="nccl",
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
                          "the multi-rank path with several ranks on one GPU)")
@@ -154,7 +157,8 @@ def main():
         worker = EngineStripWorker(eng, prec, mode=MODE_SAD_WINDOW, d_max=args.d_max, win=args.win)
 
     def step():
-        return sharded_depth(worker, frames, H, W, dst=0 if world > 1 else None)
+        return sharded_depth(worker, frames, H, W, dst=0 if world > 1 else None,
+                             interleave=args.interleave if args.mode == "ring" else 0)
 
     def fence():
         torch.cuda.synchronize()
@@ -183,10 +187,13 @@ def main():
     probes_pp = None
     if args.mode == "ring":
         r0, r1 = strip_bounds(H, world)[rank]
+        pat = None
+        if args.interleave and world > 1:
+            r0, r1, pat = 0, H, (args.interleave, world, rank)
         eng.stats_enable(True)
         tot_p = tot_g = 0
         for f in frames[: min(len(frames), 8)]:
-            worker.match_strip(f, (r0, r1))
+            worker.match_strip(f, (r0, r1), pattern=pat)
             s = eng.stats()
             tot_p += s["probes"]
             tot_g += s["groups"]
@@ -197,7 +204,7 @@ def main():
         px_step = n_frames * W * H
         value = px_step * args.steps / dt / 1e6
         strip_rows = strip_bounds(H, world)[0]
-        px_launch = (strip_rows[1] - strip_rows[0]) * W
+        px_launch = (strip_rows[1] - strip_rows[0]) * W  # ~H/world rows per launch either way
         k_avg_ms = kms / max(klaunches, 1)
         achieved = ALGO_BYTES_PER_PIXEL * px_launch / (k_avg_ms * 1e-3) / 1e9 if klaunches else 0.0
         # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE,
@@ -226,7 +233,9 @@ def main():
                              + f", precision [{args.precision};3]"),
                 "frames_per_step": n_frames, "width": W, "height": H, "d_max": args.d_max,
                 "mode": args.mode,
-                "parallelism": (f"row strips x{world} + all_reduce(max) + gather of rows to rank 0 (RCCL)"
+                "parallelism": ((f"interleaved {args.interleave}-row strips" if args.interleave and args.mode == "ring"
+                                 else "contiguous row strips")
+                                + f" x{world} + all_reduce(max) + gather of rows to rank 0 (RCCL)"
                                 if world > 1 else "single GPU"),
             },
             "roofline": {

@@ -101,6 +101,11 @@ typedef struct {
     uint32_t row_begin, row_end; /* main-image rows to compute; 0,0 = all.  A group belongs
                                     to the strip when its top row y is inside it */
     uint32_t flags;        /* STEPTH_FLAG_* */
+    /* interleaved row blocks (ring mode, uniform tiles): inside [row_begin,row_end) the call
+     * owns only rows y with (y / row_block) % row_mod == row_rem; row_block == 0 = all rows.
+     * row_block must be even and a multiple of tile_h.  The work per row is very uneven
+     * (data dependent), so N ranks balance best with row_mod = N, row_rem = rank. */
+    uint32_t row_block, row_mod, row_rem;
 } stepth_params;
 
 /* counters of the last ring-mode call, for "mean probes/pixel" reporting */
@@ -154,6 +159,12 @@ int stepth_depth_from_additional(stepth_engine *engine, const stepth_image *main
  */
 int stepth_normalise_rows(stepth_engine *engine, const stepth_image *rows,
                           const uint32_t *max_ptr, uint32_t max_memory, uint32_t flags);
+/* The same restricted to the rows of an interleaved pattern (see stepth_params.row_block):
+ * `rows` starts at absolute image row `first_row`. */
+int stepth_normalise_rows_pattern(stepth_engine *engine, const stepth_image *rows,
+                                  uint32_t first_row, uint32_t row_block, uint32_t row_mod,
+                                  uint32_t row_rem, const uint32_t *max_ptr,
+                                  uint32_t max_memory, uint32_t flags);
 
 /*
  * The tail alone, src/depth_image.rs:133-134: DynamicImage::resize(w, h, Gaussian) of a Luma8

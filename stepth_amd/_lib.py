@@ -49,7 +49,8 @@ class Params(C.Structure):
                 ("precision", C.c_uint8 * 3), ("reserved0", C.c_uint8),
                 ("max_steps", C.c_uint32), ("tile_w", C.c_uint32), ("tile_h", C.c_uint32),
                 ("d_max", C.c_uint32), ("win", C.c_uint32), ("row_begin", C.c_uint32),
-                ("row_end", C.c_uint32), ("flags", C.c_uint32)]
+                ("row_end", C.c_uint32), ("flags", C.c_uint32), ("row_block", C.c_uint32),
+                ("row_mod", C.c_uint32), ("row_rem", C.c_uint32)]
 
 
 class Stats(C.Structure):
@@ -74,6 +75,9 @@ SYMBOLS = {
                                                C.c_void_p]),
     "stepth_normalise_rows": (C.c_int, [C.c_void_p, _P(Image), C.c_void_p, C.c_uint32,
                                         C.c_uint32]),
+    "stepth_normalise_rows_pattern": (C.c_int, [C.c_void_p, _P(Image), C.c_uint32, C.c_uint32,
+                                                C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32,
+                                                C.c_uint32]),
     "stepth_gaussian_same_size": (C.c_int, [C.c_void_p, _P(Image), _P(Image), C.c_uint32]),
     "stepth_distance_dot_array_batch": (C.c_int, [C.c_void_p, _P(Image), C.c_void_p, C.c_void_p,
                                                   C.c_size_t, C.c_uint32, C.c_void_p,

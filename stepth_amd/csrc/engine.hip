@@ -23,7 +23,7 @@ using namespace stepth;
 
 static_assert(sizeof(stepth_group) == 20 && sizeof(GroupRec) == 20, "group layout");
 static_assert(sizeof(Query) == 16, "query layout");
-static_assert(sizeof(stepth_params) == 44 && sizeof(stepth_image) == 32 && sizeof(stepth_stats) == 56,
+static_assert(sizeof(stepth_params) == 56 && sizeof(stepth_image) == 32 && sizeof(stepth_stats) == 56,
               "C-ABI struct layout (mirrored by stepth_amd/_lib.py)");
 
 namespace {
@@ -177,6 +177,8 @@ struct KernelTimer { // brackets the dominant kernel with events when timing is 
 
 
 // RGB8 additional image -> tiled cells T + block bounds BB (src/depth_image.rs:96-100)
+// Also clears the engine's words (max, pending count, run counters) for the kernels that
+// follow: one launch less than a memset.
 int pack_additional(stepth_engine *e, const uint8_t *d_add, size_t stride, uint32_t wa,
                     uint32_t ha, uint32_t &bw, uint32_t &bh, uint32_t row_lo = 0,
                     uint32_t row_hi = 0xFFFFFFFFu)
@@ -193,7 +195,7 @@ int pack_additional(stepth_engine *e, const uint8_t *d_add, size_t stride, uint3
     row_lo = std::min(row_lo, row_hi);
     const uint32_t by0 = row_lo / 8u, by1 = std::max((row_hi + 7u) / 8u, by0 + 1u);
     PackArgs pa{d_add, stride, wa, ha, bw, bh, (uint32_t *)e->T.p, (uint2 *)e->BB.p, by0,
-                std::min(by1, bh) - by0};
+                std::min(by1, bh) - by0, e->words, (uint32_t)(kWordsBytes / 4)};
     hipLaunchKernelGGL(pack_additional_kernel, dim3((bw * pa.nby + 3u) / 4u), dim3(256), 0,
                        e->stream, pa);
     const uint32_t sbw = (bw + 7u) / 8u, sbh = (bh + 7u) / 8u;
@@ -516,6 +518,16 @@ int stepth_depth_from_additional(stepth_engine *e, const stepth_image *main_im,
         row1 = H;
     if (row0 > row1 || row1 > H)
         return fail(e, STEPTH_ERR_BAD_ARG, "row strip [%u,%u) outside 0..%u", row0, row1, H);
+    RowPattern rp{0u, 1u, 0u};
+    if (p.row_block) {
+        if (p.mode != STEPTH_MODE_RING_FIRST_HIT || groups || (p.row_block & 1u) ||
+            p.row_mod == 0 || p.row_rem >= p.row_mod || p.tile_h == 0 ||
+            p.row_block % p.tile_h != 0 || (p.flags & STEPTH_FLAG_GAUSSIAN_TAIL))
+            return fail(e, STEPTH_ERR_BAD_ARG,
+                        "row pattern: ring mode with uniform tiles only, even row_block that is "
+                        "a multiple of tile_h, row_rem < row_mod, no Gaussian tail");
+        rp = RowPattern{p.row_block, p.row_mod, p.row_rem};
+    }
     HIP_TRY(e, hipSetDevice(e->device));
 
     const uint8_t *d_main = nullptr, *d_add = nullptr;
@@ -532,11 +544,18 @@ int stepth_depth_from_additional(stepth_engine *e, const stepth_image *main_im,
         os = (W + 15u) & ~15u;
         TRY(reserve(e, e->stage_out, os * H));
         d_out = static_cast<uint8_t *>(e->stage_out.p);
+        if (rp.block && row1 > row0) // rows of other ranks must come back unchanged
+            HIP_TRY(e, hipMemcpy2DAsync(d_out + (size_t)row0 * os, os,
+                                        static_cast<const uint8_t *>(depth_im->data) +
+                                            (size_t)row0 * depth_im->stride,
+                                        depth_im->stride, W, row1 - row0, hipMemcpyHostToDevice,
+                                        e->stream));
     }
 
-    HIP_TRY(e, hipMemsetAsync(e->words, 0, kWordsBytes, e->stream));
+    bool max_published = false; // a paint kernel already stored the max at max_out
 
     if (p.mode == STEPTH_MODE_SAD_WINDOW) {
+        HIP_TRY(e, hipMemsetAsync(e->words, 0, kWordsBytes, e->stream));
         if (groups)
             return fail(e, STEPTH_ERR_BAD_ARG, "SAD mode takes no group list");
         if (add_im->width != W || add_im->height != H)
@@ -584,6 +603,8 @@ int stepth_depth_from_additional(stepth_engine *e, const stepth_image *main_im,
             PaintArgs pa{};
             pa.raw = sa.raw;
             pa.max_word = e->words;
+            pa.max_out = async ? max_out : nullptr;
+            max_published = async && max_out;
             pa.identity = raw_only;
             pa.out = d_out;
             pa.ostride = os;
@@ -605,7 +626,7 @@ int stepth_depth_from_additional(stepth_engine *e, const stepth_image *main_im,
             // uniform tiles lie in rows [row0/2, (row1+tile_h)/2], every search stays within
             // max_steps-1 rings of its centre (group lists: unknown centres, pack everything)
             uint32_t lo = 0, hi = 0xFFFFFFFFu;
-            if (!groups && p.tile_h && p.max_steps < 0x40000000u) {
+            if (!groups && p.tile_h && p.max_steps < 0x40000000u) { // (a pattern keeps row0..row1)
                 const uint32_t reach = p.max_steps ? p.max_steps - 1u : 0u;
                 const uint32_t c_lo = row0 / 2u, c_hi = (row1 + p.tile_h) / 2u;
                 lo = c_lo > reach ? c_lo - reach : 0u;
@@ -630,6 +651,7 @@ int stepth_depth_from_additional(stepth_engine *e, const stepth_image *main_im,
 
         PaintArgs pa{};
         pa.max_word = e->words;
+        pa.max_out = async ? max_out : nullptr;
         pa.identity = raw_only;
         pa.out = d_out;
         pa.ostride = os;
@@ -637,6 +659,7 @@ int stepth_depth_from_additional(stepth_engine *e, const stepth_image *main_im,
         pa.h = H;
         pa.row_begin = row0;
         pa.row_end = row1;
+        pa.rp = rp;
 
         const uint32_t rows = row1 - row0;
         int qmode;
@@ -694,6 +717,13 @@ int stepth_depth_from_additional(stepth_engine *e, const stepth_image *main_im,
                 ra.ntx = (W >> 1) + 1u;
                 ra.ty0 = (row0 + 1u) >> 1;
                 ra.n_slots = rows ? ra.ntx * ((row1 >> 1) - ra.ty0 + 1u) * 4u : 0u;
+                ra.rp = rp;
+                if (rp.block) {
+                    // owned blocks b = rem, rem+mod, ... with b*block < H
+                    const uint32_t nb_all = (H + rp.block - 1u) / rp.block;
+                    const uint32_t nb = nb_all > rp.rem ? (nb_all - rp.rem + rp.mod - 1u) / rp.mod : 0u;
+                    ra.n_slots = rows ? ra.ntx * nb * (rp.block / 2u + 1u) * 4u : 0u;
+                }
                 qmode = 0;
             } else {
                 TRY(reserve(e, e->queries, (size_t)std::max(ra.n, 1u) * sizeof(Query)));
@@ -710,6 +740,7 @@ int stepth_depth_from_additional(stepth_engine *e, const stepth_image *main_im,
                 pr.n = ra.n;
                 pr.row_begin = row0;
                 pr.row_end = row1;
+                pr.rp = rp;
                 memcpy(pr.prec, p.precision, 3);
                 pr.out = (Query *)e->queries.p;
                 if (ra.n) {
@@ -733,6 +764,7 @@ int stepth_depth_from_additional(stepth_engine *e, const stepth_image *main_im,
         pa.groups = d_groups;
         pa.n = ra.n;
         if (rows && ra.n) {
+            max_published = async && max_out;
             if (groups) {
                 hipLaunchKernelGGL(paint_list_kernel, dim3((ra.n + 3) / 4), dim3(256), 0, e->stream, pa);
             } else if (qmode == 0 && (W & 3u) == 0 && (os & 3u) == 0 &&
@@ -759,7 +791,7 @@ int stepth_depth_from_additional(stepth_engine *e, const stepth_image *main_im,
     }
 
     if (async) {
-        if (max_out)
+        if (max_out && !max_published)
             HIP_TRY(e, hipMemcpyAsync(max_out, e->words, 4, hipMemcpyDeviceToDevice, e->stream));
         return STEPTH_OK;
     }
@@ -781,8 +813,9 @@ int stepth_depth_from_additional(stepth_engine *e, const stepth_image *main_im,
     return STEPTH_OK;
 }
 
-int stepth_normalise_rows(stepth_engine *e, const stepth_image *rows, const uint32_t *max_ptr,
-                          uint32_t max_memory, uint32_t flags)
+int stepth_normalise_rows_pattern(stepth_engine *e, const stepth_image *rows, uint32_t first_row,
+                                  uint32_t row_block, uint32_t row_mod, uint32_t row_rem,
+                                  const uint32_t *max_ptr, uint32_t max_memory, uint32_t flags)
 {
     if (!e)
         return STEPTH_ERR_BAD_ARG;
@@ -804,7 +837,11 @@ int stepth_normalise_rows(stepth_engine *e, const stepth_image *rows, const uint
         HIP_TRY(e, hipMemcpyAsync(e->words + 1, &mx_host, 4, hipMemcpyHostToDevice, e->stream));
         d_max = e->words + 1;
     }
+    if (row_block && (row_mod == 0 || row_rem >= row_mod))
+        return fail(e, STEPTH_ERR_BAD_ARG, "row pattern: row_rem must be < row_mod");
     NormArgs na{};
+    na.first_row = first_row;
+    na.rp = RowPattern{row_block, row_block ? row_mod : 1u, row_block ? row_rem : 0u};
     na.w = rows->width;
     na.rows = rows->height;
     na.max_word = d_max;
@@ -831,6 +868,12 @@ int stepth_normalise_rows(stepth_engine *e, const stepth_image *rows, const uint
     if (mx_host == 0)
         return fail(e, STEPTH_ERR_MAX_ZERO, "max is 0; rows zeroed");
     return STEPTH_OK;
+}
+
+int stepth_normalise_rows(stepth_engine *e, const stepth_image *rows, const uint32_t *max_ptr,
+                          uint32_t max_memory, uint32_t flags)
+{
+    return stepth_normalise_rows_pattern(e, rows, 0, 0, 1, 0, max_ptr, max_memory, flags);
 }
 
 int stepth_gaussian_same_size(stepth_engine *e, const stepth_image *src, const stepth_image *dst,
@@ -904,7 +947,6 @@ int stepth_distance_dot_array_batch(stepth_engine *e, const stepth_image *array,
     TRY(reserve(e, e->aux_found, std::max<size_t>(n, 4)));
     HIP_TRY(e, hipMemcpyAsync(e->queries.p, qs.data(), n * sizeof(Query), hipMemcpyHostToDevice,
                               e->stream));
-    HIP_TRY(e, hipMemsetAsync(e->words, 0, kWordsBytes, e->stream));
     RingArgs ra{};
     ra.T = (const uint32_t *)e->T.p;
     ra.BB = (const uint2 *)e->BB.p;

@@ -34,6 +34,8 @@ struct PackArgs {
     uint32_t *T;
     uint2 *BB;
     uint32_t by0, nby; // block rows to pack (a row strip only reaches part of the image)
+    uint32_t *zero;    // words to clear for the kernels that follow (max, counters) ...
+    uint32_t n_zero;   // ... instead of a separate memset launch
 };
 
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
@@ -55,6 +57,9 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
 __global__ __launch_bounds__(256) void pack_additional_kernel(PackArgs a)
 {
     const uint32_t lane = threadIdx.x & 63u;
+    if (blockIdx.x == 0)
+        for (uint32_t i = threadIdx.x; i < a.n_zero; i += blockDim.x)
+            a.zero[i] = 0u;
     const uint32_t idx = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (idx >= a.bw * a.nby)
         return;
@@ -115,6 +120,16 @@ __global__ __launch_bounds__(256) void pack_super_kernel(SuperArgs a)
         a.SB[sb] = make_uint2(pack_cell(mx[0], mx[1], mx[2]), pack_cell(mn[0], mn[1], mn[2]));
 }
 
+// Rows a call owns inside [row_begin,row_end): all of them (block == 0), or every mod-th block
+// of `block` rows -- interleaved row blocks balance the data-dependent work between ranks.
+struct RowPattern {
+    uint32_t block, mod, rem;
+    __device__ __forceinline__ bool owns(uint32_t y) const
+    {
+        return block == 0u || (y / block) % mod == rem;
+    }
+};
+
 // ---------------------------------------------------------------------------------------
 // Queries.  One query = one disage group (src/depth_image.rs:113-121): the search centre
 // `middle` and the colour box of its value.
@@ -134,6 +149,7 @@ struct PrepArgs {
     const void *groups; // stepth_group[n]
     uint32_t n;
     uint32_t row_begin, row_end;
+    RowPattern rp;
     uint8_t prec[3];
     Query *out;
 };
@@ -171,6 +187,8 @@ __global__ __launch_bounds__(256) void prep_tiles_kernel(PrepArgs a)
     Query q;
     q.cx = (x + w) / 2u; // depth_image.rs:115
     q.cy = (y + h) / 2u; // depth_image.rs:116
+    if (!a.rp.owns(y))
+        q.cx = q.cy = ~0u; // another rank's tile row
     make_box(v, a.prec, q.lo, q.hi);
     a.out[g] = q;
 }
@@ -235,6 +253,7 @@ struct RingArgs {
     size_t mstride;
     uint32_t mch, w, row0, row1;
     uint32_t ntx, ty0, n_slots; // 2x2 tiles of the strip: columns, first tile row, slots
+    RowPattern rp;              // with a pattern: slots walk the owned row blocks only
     // QMODE 1: prepared queries
     const Query *queries;
     uint32_t n;
@@ -353,9 +372,20 @@ __device__ __forceinline__ bool load_query(const RingArgs &a, uint32_t slot, uin
 {
     if constexpr (QMODE == 0) {
         const uint32_t tile = slot >> 2, m = slot & 3u;
-        const uint32_t tx = tile % a.ntx, ty = a.ty0 + tile / a.ntx;
+        const uint32_t tx = tile % a.ntx;
+        uint32_t ty = a.ty0 + tile / a.ntx, y_lo = a.row0, y_hi = a.row1;
+        if (a.rp.block) {
+            // k-th owned block of rows = global block rem + k*mod; it touches block/2 + 1
+            // tile rows (its first and last one are shared with the neighbouring blocks, which
+            // emit the rows on their side)
+            const uint32_t per = a.rp.block / 2u + 1u, tr = tile / a.ntx;
+            const uint32_t y0 = (a.rp.rem + (tr / per) * a.rp.mod) * a.rp.block;
+            ty = y0 / 2u + tr % per;
+            y_lo = max(y_lo, y0);
+            y_hi = min(y_hi, y0 + a.rp.block);
+        }
         const uint32_t x = 2u * tx - 1u + (m & 1u), y = 2u * ty - 1u + (m >> 1); // may wrap
-        if (slot >= a.n_slots || x >= a.w || y < a.row0 || y >= a.row1)
+        if (slot >= a.n_slots || x >= a.w || y < y_lo || y >= y_hi)
             return false;
         q = (y - a.row0) * a.w + x;
         const uint8_t *p = a.main_px + (size_t)y * a.mstride + (size_t)x * a.mch;
@@ -499,28 +529,40 @@ __global__ __launch_bounds__(256) STEPTH_SEARCH_ATTR void ring_search_kernel(Sea
     // Runs of kRun consecutive pending records are dealt from kParts interleaved partitions
     // (run r belongs to partition r % kParts), each with its own counter on its own cache
     // line: a single counter would cap the whole chip at ~88 grabs/us.  A wave starts at
-    // partition wave % kParts and moves on when one is empty.
-    const uint32_t n_runs = (count + kRun - 1u) / kRun;
+    // partition wave % kParts and moves on when it is empty.
+    // long runs amortise the grab, short runs balance small launches (a row strip of 1/8
+    // frame has only ~24 records per wave): aim at >= 8 runs per resident wave
+    const uint32_t run = count >= 8192u * 8u * 12u ? kRun : count >= 8192u * 8u * 8u ? 8u : 4u;
+    const uint32_t n_runs = (count + run - 1u) / run;
     const uint32_t wave_id =
         (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (threadIdx.x >> 6)));
-    uint32_t part = wave_id % kParts, empty = 0;
+    static_assert(kParts <= 64, "one lane per partition in the refill scan");
+    uint32_t part = wave_id % kParts;
     for (;;) {
         const uint32_t part_runs = (n_runs + kParts - 1u - part) / kParts;
-        uint32_t *ctr = a.next + part * kPartStride;
-        uint32_t idx = part_runs;
-        if (lane == 0 &&
-            __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < part_runs)
-            idx = atomicAdd(ctr, 1u);
+        uint32_t idx = 0;
+        if (lane == 0)
+            idx = atomicAdd(a.next + part * kPartStride, 1u);
         idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)idx);
         if (idx >= part_runs) {
-            if (++empty == kParts)
+            // this partition is exhausted: look at all of them at once (lane p reads counter
+            // p) and move to the next one that still has runs; none left -> done
+            bool has = false;
+            if (lane < kParts) {
+                const uint32_t taken = __hip_atomic_load(a.next + lane * kPartStride,
+                                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                has = taken < (n_runs + kParts - 1u - lane) / kParts;
+            }
+            const unsigned long long live = ballot(has);
+            if (!live)
                 break;
-            part = part + 1u == kParts ? 0u : part + 1u;
+            // first live partition after `part`, cyclically
+            const unsigned long long after = part + 1u < 64u ? live >> (part + 1u) : 0ull;
+            part = after ? part + 1u + (uint32_t)(__ffsll(after) - 1) : (uint32_t)(__ffsll(live) - 1);
             continue;
         }
-        empty = 0;
-        const uint32_t run0 = (idx * kParts + part) * kRun;
-        const uint32_t run_len = min(kRun, count - run0);
+        const uint32_t run0 = (idx * kParts + part) * run;
+        const uint32_t run_len = min(run, count - run0);
         // one coalesced read brings the whole run: lane i holds record run0 + i
         Query rec = Query{0u, 0u, 0u, 0u};
         if (lane < run_len)
@@ -838,8 +880,11 @@ __global__ __launch_bounds__(256) void ring_finish_kernel(FinishArgs a)
 // (v,max <= 255); a 256-entry table per workgroup replaces the per-pixel division.
 // max == 0: the reference panics (:127); the table is all zero.  identity != 0: RAW_ONLY.
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ void build_lut(uint8_t *lut, const uint32_t *max_word, int identity)
+__device__ __forceinline__ void build_lut(uint8_t *lut, const uint32_t *max_word, int identity,
+                                          uint32_t *max_out = nullptr)
 {
+    if (max_out && blockIdx.x == 0 && threadIdx.x == 0)
+        *max_out = *max_word;
     const uint32_t mx = identity ? 255u : *max_word;
     for (uint32_t v = threadIdx.x; v < 256u; v += blockDim.x)
         lut[v] = (mx == 0) ? 0 : (uint8_t)(v * 255u / mx);
@@ -849,11 +894,13 @@ __device__ __forceinline__ void build_lut(uint8_t *lut, const uint32_t *max_word
 struct PaintArgs {
     const uint8_t *raw; // per group
     const uint32_t *max_word;
+    uint32_t *max_out; // optional: the caller's copy of the max (device memory)
     int identity;
     uint8_t *out; // [H][W], points at row 0 of the image
     size_t ostride;
     uint32_t w, h;
     uint32_t row_begin, row_end;
+    RowPattern rp;
     uint32_t tile_w, tile_h, gx; // uniform tiles
     const void *groups;          // or list
     uint32_t n;
@@ -863,13 +910,15 @@ struct PaintArgs {
 __global__ __launch_bounds__(256) void paint_tiles_kernel(PaintArgs a)
 {
     __shared__ uint8_t lut[256];
-    build_lut(lut, a.max_word, a.identity);
+    build_lut(lut, a.max_word, a.identity, a.max_out);
     const uint32_t rows = a.row_end - a.row_begin;
     const size_t total = (size_t)rows * a.w;
     const uint32_t gy0 = a.row_begin / a.tile_h;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (size_t)gridDim.x * blockDim.x) {
         const uint32_t y = a.row_begin + (uint32_t)(i / a.w), x = (uint32_t)(i % a.w);
+        if (!a.rp.owns(y))
+            continue;
         const size_t g = (size_t)(y / a.tile_h - gy0) * a.gx + x / a.tile_w;
         a.out[(size_t)y * a.ostride + x] = lut[a.raw[g]];
     }
@@ -879,12 +928,14 @@ __global__ __launch_bounds__(256) void paint_tiles_kernel(PaintArgs a)
 __global__ __launch_bounds__(256) void paint_1x1_vec4_kernel(PaintArgs a)
 {
     __shared__ uint8_t lut[256];
-    build_lut(lut, a.max_word, a.identity);
+    build_lut(lut, a.max_word, a.identity, a.max_out);
     const uint32_t rows = a.row_end - a.row_begin, w4 = a.w >> 2;
     const size_t total = (size_t)rows * w4;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (size_t)gridDim.x * blockDim.x) {
         const uint32_t r = (uint32_t)(i / w4), c = (uint32_t)(i % w4);
+        if (!a.rp.owns(a.row_begin + r))
+            continue;
         const uint32_t v = reinterpret_cast<const uint32_t *>(a.raw)[i];
         const uint32_t o = (uint32_t)lut[v & 0xff] | ((uint32_t)lut[(v >> 8) & 0xff] << 8) |
                            ((uint32_t)lut[(v >> 16) & 0xff] << 16) |
@@ -899,7 +950,7 @@ __global__ __launch_bounds__(256) void paint_1x1_vec4_kernel(PaintArgs a)
 __global__ __launch_bounds__(256) void paint_list_kernel(PaintArgs a)
 {
     __shared__ uint8_t lut[256];
-    build_lut(lut, a.max_word, a.identity);
+    build_lut(lut, a.max_word, a.identity, a.max_out);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t g = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (g >= a.n)
@@ -922,6 +973,8 @@ struct NormArgs {
     size_t stride;
     uint32_t w, rows;
     const uint32_t *max_word;
+    uint32_t first_row; // absolute row of data's row 0, for the pattern
+    RowPattern rp;
 };
 
 __global__ __launch_bounds__(256) void normalise_rows_kernel(NormArgs a)
@@ -931,6 +984,8 @@ __global__ __launch_bounds__(256) void normalise_rows_kernel(NormArgs a)
     const size_t total = (size_t)a.rows * a.w;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (size_t)gridDim.x * blockDim.x) {
+        if (!a.rp.owns(a.first_row + (uint32_t)(i / a.w)))
+            continue;
         uint8_t *p = a.data + (size_t)(i / a.w) * a.stride + (i % a.w);
         *p = lut[*p];
     }

@@ -124,8 +124,10 @@ class Engine:
     def depth_from_additional(self, main, additional, precision, *, max_steps: int = 255,
                               tile: Tuple[int, int] = (1, 1), groups=None,
                               mode: int = L.MODE_RING_FIRST_HIT, d_max: int = 0, win: int = 0,
-                              rows: Optional[Tuple[int, int]] = None, raw_only: bool = False,
-                              gaussian_tail: bool = False, out=None, max_out=None,
+                              rows: Optional[Tuple[int, int]] = None,
+                              row_pattern: Optional[Tuple[int, int, int]] = None,
+                              raw_only: bool = False, gaussian_tail: bool = False, out=None,
+                              max_out=None,
                               asynchronous: bool = False):
         """stepth_depth_from_additional.  Returns (depth [H,W] u8, max or None).
 
@@ -156,6 +158,8 @@ class Engine:
             p.row_begin, p.row_end = rows
             if rows[0] == rows[1]:
                 return out, 0  # empty strip; 0,0 would mean "all rows" in the C-ABI
+        if row_pattern is not None:  # (row_block, row_mod, row_rem): interleaved row blocks
+            p.row_block, p.row_mod, p.row_rem = row_pattern
         p.flags = ((L.FLAG_ASYNC if asynchronous else 0) | (L.FLAG_RAW_ONLY if raw_only else 0) |
                    (L.FLAG_GAUSSIAN_TAIL if gaussian_tail else 0))
         gptr, gn, gmem, k4 = None, 0, L.MEM_HOST, None
@@ -180,18 +184,23 @@ class Engine:
         self._check(st)
         return out, int(mx.value)
 
-    def normalise_rows(self, rows, max_value, asynchronous: bool = False):
-        """stepth_normalise_rows, in place.  max_value: int (host) or CUDA tensor (device)."""
+    def normalise_rows(self, rows, max_value, asynchronous: bool = False, first_row: int = 0,
+                       row_pattern: Optional[Tuple[int, int, int]] = None):
+        """stepth_normalise_rows[_pattern], in place.  max_value: int (host) or CUDA tensor
+        (device).  With `row_pattern` = (row_block, row_mod, row_rem) only the owned rows of
+        the view, whose row 0 is image row `first_row`, are touched."""
         ri, _k = _describe(rows, (1,), "rows")
         flags = L.FLAG_ASYNC if asynchronous else 0
+        rb, rm, rr = row_pattern if row_pattern is not None else (0, 1, 0)
         if _is_tensor(max_value):
-            st = self._lib.stepth_normalise_rows(self._h, C.byref(ri), max_value.data_ptr(),
-                                                 L.MEM_DEVICE, flags)
+            st = self._lib.stepth_normalise_rows_pattern(self._h, C.byref(ri), first_row, rb, rm,
+                                                         rr, max_value.data_ptr(), L.MEM_DEVICE,
+                                                         flags)
         else:
             mx = C.c_uint32(int(max_value))
-            st = self._lib.stepth_normalise_rows(self._h, C.byref(ri),
-                                                 C.cast(C.byref(mx), C.c_void_p), L.MEM_HOST,
-                                                 flags)
+            st = self._lib.stepth_normalise_rows_pattern(self._h, C.byref(ri), first_row, rb, rm,
+                                                         rr, C.cast(C.byref(mx), C.c_void_p),
+                                                         L.MEM_HOST, flags)
         self._check(st)
         return rows
 

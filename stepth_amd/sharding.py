@@ -38,12 +38,18 @@ def strip_bounds(height: int, world: int, tile_h: int = 1) -> List[Tuple[int, in
 class StripWorker:
     """What a rank must be able to do for one frame."""
 
-    def match_strip(self, frame, rows: Tuple[int, int]) -> Tuple[torch.Tensor, torch.Tensor]:
-        """PASS 1 on rows [r0,r1): -> (raw u8 [r1-r0, W], max int32 [1]), same device."""
+    def match_strip(self, frame, rows: Tuple[int, int], max_out: Optional[torch.Tensor] = None,
+                    pattern: Optional[Tuple[int, int, int]] = None
+                    ) -> Tuple[torch.Tensor, torch.Tensor]:
+        """PASS 1 on rows [r0,r1): -> (raw u8 [r1-r0, W], max int32 [1]), same device.
+        `max_out`, when given, is a zeroed int32 [1] view to write the max into.  With
+        `pattern` = (row_block, row_mod, row_rem) only rows y of the range with
+        (y // row_block) % row_mod == row_rem are computed (the others are left untouched)."""
         raise NotImplementedError
 
-    def normalise(self, rows: torch.Tensor, max_word: torch.Tensor) -> None:
-        """PASS 2 in place: rows = rows*255/max (0 when max == 0)."""
+    def normalise(self, rows: torch.Tensor, max_word: torch.Tensor, first_row: int = 0,
+                  pattern: Optional[Tuple[int, int, int]] = None) -> None:
+        """PASS 2 in place: rows = rows*255/max (0 when max == 0), owned rows only."""
         raise NotImplementedError
 
 
@@ -56,49 +62,78 @@ class EngineStripWorker(StripWorker):
         self.kw = dict(max_steps=max_steps, tile=tile, mode=mode, d_max=d_max, win=win)
         self.precision = list(precision)
 
-    def match_strip(self, frame, rows):
+    def match_strip(self, frame, rows, max_out=None, pattern=None):
         main, add = frame
         h, w = main.shape[0], main.shape[1]
         full = torch.empty((h, w), dtype=torch.uint8, device=main.device)
-        mx = torch.zeros(1, dtype=torch.int32, device=main.device)
+        mx = max_out if max_out is not None else torch.zeros(1, dtype=torch.int32,
+                                                             device=main.device)
         if rows[1] > rows[0]:
             self.engine.depth_from_additional(main, add, self.precision, rows=rows,
-                                              raw_only=True, out=full, max_out=mx,
-                                              asynchronous=True, **self.kw)
+                                              row_pattern=pattern, raw_only=True, out=full,
+                                              max_out=mx, asynchronous=True, **self.kw)
         return full[rows[0]:rows[1]], mx
 
-    def normalise(self, rows, max_word):
+    def normalise(self, rows, max_word, first_row=0, pattern=None):
         if rows.shape[0]:
-            self.engine.normalise_rows(rows, max_word, asynchronous=True)
+            self.engine.normalise_rows(rows, max_word, asynchronous=True, first_row=first_row,
+                                       row_pattern=pattern)
 
 
 def sharded_depth(worker: StripWorker, frames: Sequence, height: int, width: int,
                   tile_h: int = 1, group: Optional[dist.ProcessGroup] = None,
                   device: Optional[torch.device] = None,
                   sync: Optional[Callable[[], None]] = None,
-                  dst: Optional[int] = None) -> Tuple[Optional[torch.Tensor], torch.Tensor]:
+                  dst: Optional[int] = None,
+                  interleave: int = 0) -> Tuple[Optional[torch.Tensor], torch.Tensor]:
     """Depth maps of `frames`, every frame row-strip sharded over the ranks of `group`.
 
     Returns (depth u8 [F, H, W], max int32 [F]).  Collectives per call (not per frame): one
     all_reduce(MAX) of F words and one exchange of the u8 rows -- `dst=None`: all_gather, every
     rank gets the depth maps; `dst=r`: gather to rank r only (the other ranks return None;
     each sends its own F*rows*W bytes over its own xGMI link to r, nothing else moves).
-    `sync` is called before each collective when the worker computes on a side stream."""
+    `sync` is called before each collective when the worker computes on a side stream.
+    `interleave` = B > 0 deals the rows in blocks of B (even, a multiple of tile_h): rank r owns
+    blocks r, r+world, ... of every frame -- the work per row is data dependent and very
+    uneven (one contiguous 1/8 strip of the bench frame holds 27 % of its work), interleaved
+    blocks give every rank the same mix."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
-    bounds = strip_bounds(height, world, tile_h)
-    r0, r1 = bounds[rank]
-    rows_max = max(b - a for a, b in bounds)
     n = len(frames)
+    pattern = None
+    if interleave and world > 1:
+        pattern = (interleave, world, rank)
+        owned = [torch.tensor([y for y in range(height) if (y // interleave) % world == r],
+                              dtype=torch.long) for r in range(world)]
+        bounds = [(0, height)] * world
+        r0, r1 = 0, height
+        rows_max = max(len(o) for o in owned)
+    else:
+        bounds = strip_bounds(height, world, tile_h)
+        r0, r1 = bounds[rank]
+        rows_max = max(b - a for a, b in bounds)
 
     strips, maxes = [], []
-    for f in frames:
-        raw, mx = worker.match_strip(f, (r0, r1))
+    max_buf = None
+    for i, f in enumerate(frames):
+        kw = {"pattern": pattern} if pattern else {}
+        if i == 0:
+            raw, mx = worker.match_strip(f, (r0, r1), **kw)
+            if mx.is_cuda and n > 1:  # one zeroed buffer for the other frames' maxima
+                max_buf = torch.zeros(n, dtype=torch.int32, device=mx.device)
+        elif max_buf is not None:
+            raw, mx = worker.match_strip(f, (r0, r1), max_out=max_buf[i:i + 1], **kw)
+        else:
+            raw, mx = worker.match_strip(f, (r0, r1), **kw)
         strips.append(raw)
         maxes.append(mx)
     if device is None:
         device = maxes[0].device
-    max_all = torch.cat([m.reshape(1) for m in maxes]).to(torch.int32)
+    if max_buf is not None:
+        max_buf[0:1] = maxes[0].reshape(1)
+        max_all = max_buf
+    else:
+        max_all = torch.cat([m.reshape(1) for m in maxes]).to(torch.int32)
     # gloo (CPU rehearsals of the N > 1 path) cannot gather device tensors: stage through host
     via_host = world > 1 and dist.get_backend(group) == "gloo" and max_all.is_cuda
     if world > 1:
@@ -110,14 +145,21 @@ def sharded_depth(worker: StripWorker, frames: Sequence, height: int, width: int
             max_all = m_host.to(device)
         else:
             dist.all_reduce(max_all, op=dist.ReduceOp.MAX, group=group)  # src/depth_image.rs:124
-    for i, raw in enumerate(strips):
-        worker.normalise(raw, max_all[i:i + 1])  # src/depth_image.rs:125-129
+    for i, raw in enumerate(strips):  # src/depth_image.rs:125-129
+        if pattern:
+            worker.normalise(raw, max_all[i:i + 1], first_row=r0, pattern=pattern)
+        else:
+            worker.normalise(raw, max_all[i:i + 1])
 
     if world == 1:
         return torch.stack([s for s in strips]), max_all
 
     send = torch.zeros((n, rows_max, width), dtype=torch.uint8, device=device)
-    if r1 > r0:
+    if pattern:
+        mine = owned[rank].to(device)
+        for i, raw in enumerate(strips):
+            send[i, : len(mine)] = raw.index_select(0, mine)
+    elif r1 > r0:
         for i, raw in enumerate(strips):
             send[i, : r1 - r0] = raw
     if sync:
@@ -139,6 +181,11 @@ def sharded_depth(worker: StripWorker, frames: Sequence, height: int, width: int
         else:
             dist.all_gather_into_tensor(recv.view(-1), send.view(-1), group=group)
     depth = torch.empty((n, height, width), dtype=torch.uint8, device=device)
+    if pattern:
+        for r in range(world):
+            if len(owned[r]):
+                depth[:, owned[r].to(device)] = recv[r, :, : len(owned[r])]
+        return depth, max_all
     for r, (a, b) in enumerate(bounds):
         if b > a:
             depth[:, a:b] = recv[r, :, : b - a]

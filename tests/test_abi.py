@@ -48,7 +48,7 @@ def test_struct_layouts():
     from oracle import oracle as O
     assert C.sizeof(_lib.Group) == 20 == GROUP_DTYPE.itemsize == O.GROUP_DTYPE.itemsize
     assert C.sizeof(_lib.Image) == 32
-    assert C.sizeof(_lib.Params) == 44  # static_assert'ed in csrc/engine.hip
+    assert C.sizeof(_lib.Params) == 56  # static_assert'ed in csrc/engine.hip
     assert C.sizeof(_lib.Stats) == 56
     assert _lib.Params.flags.offset == 40 and _lib.Params.max_steps.offset == 12
 

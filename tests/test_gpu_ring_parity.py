@@ -326,6 +326,36 @@ def test_strips_with_short_reach_pack_only_part_of_the_additional_image(engine, 
         assert max(maxes) == ref["max"]
 
 
+@pytest.mark.parametrize("tile,block", [((1, 1), 2), ((1, 1), 16), ((1, 1), 6), ((4, 4), 8), ((5, 2), 10)])
+def test_interleaved_row_blocks_compose_to_the_full_frame(engine, oracle, tile, block):
+    """rank r of N owns row blocks r, r+N, ...: PASS 1 per rank, max over ranks, PASS 2 per
+    rank -- every pixel exactly once, result identical to the single call"""
+    from stepth_amd import synth
+    l, r, _ = synth.stereo_pair(173, 141, 32, seed=31)
+    ref = oracle.depth_from_additional(l, r, P36, 255, tile)
+    for world in (2, 3, 8):
+        out = np.full((141, 173), 0xAB, np.uint8)
+        maxes = []
+        for rank in range(world):
+            before = out.copy()
+            _, mx = engine.depth_from_additional(l, r, P36, tile=tile, raw_only=True, out=out,
+                                                 row_pattern=(block, world, rank))
+            maxes.append(mx)
+            ys = np.arange(141)
+            other = (ys // block) % world != rank
+            np.testing.assert_array_equal(out[other], before[other])  # nothing else touched
+        np.testing.assert_array_equal(out, ref["raw"])
+        assert max(maxes) == ref["max"]
+        for rank in range(world):
+            engine.normalise_rows(out, max(maxes), row_pattern=(block, world, rank))
+        np.testing.assert_array_equal(out, ref["depth"])
+    from stepth_amd import StepthError
+    with pytest.raises(StepthError):
+        engine.depth_from_additional(l, r, P36, row_pattern=(3, 2, 0))   # odd block
+    with pytest.raises(StepthError):
+        engine.depth_from_additional(l, r, P36, row_pattern=(4, 2, 2))   # rem >= mod
+
+
 def test_device_memory_async_path(engine, oracle):
     import torch
     from stepth_amd import synth

@@ -21,12 +21,15 @@ class OracleStripWorker:
         from oracle import oracle as O
         self.O, self.prec, self.max_steps, self.tile = O, prec, max_steps, tile
 
-    def match_strip(self, frame, rows):
+    def match_strip(self, frame, rows, max_out=None, pattern=None):
         main, add = frame
         O = self.O
         h, w = main.shape[:2]
         g = O.uniform_groups(main, *self.tile)
-        sel = g[(g["y"] >= rows[0]) & (g["y"] < rows[1])]
+        keep = (g["y"] >= rows[0]) & (g["y"] < rows[1])
+        if pattern:
+            keep &= (g["y"] // pattern[0]) % pattern[1] == pattern[2]
+        sel = g[keep]
         out = np.zeros((h, w), np.uint8)
         mx = 0
         if len(sel):
@@ -35,11 +38,16 @@ class OracleStripWorker:
             mx = int(m["raw"].max())
         return torch.from_numpy(out[rows[0]:rows[1]].copy()), torch.tensor([mx], dtype=torch.int32)
 
-    def normalise(self, rows, max_word):
+    def normalise(self, rows, max_word, first_row=0, pattern=None):
         mx = int(max_word.item())
         if rows.numel():
             v = rows.to(torch.int32) * 255 // max(mx, 1) if mx else rows.to(torch.int32) * 0
-            rows.copy_(v.to(torch.uint8))
+            if pattern:
+                ys = torch.arange(first_row, first_row + rows.shape[0])
+                own = (ys // pattern[0]) % pattern[1] == pattern[2]
+                rows[own] = v.to(torch.uint8)[own]
+            else:
+                rows.copy_(v.to(torch.uint8))
 
 
 def _free_port():
@@ -50,7 +58,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, tile, q, dst=None):
+def _worker(rank, world, port, tile, q, dst=None, interleave=0):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -62,7 +70,8 @@ def _worker(rank, world, port, tile, q, dst=None):
             l, r, _ = synth.stereo_pair(97, 61, 16, seed=seed)
             frames.append((l, r))
         wk = OracleStripWorker([36] * 3, 64, tile)
-        depth, mx = sharded_depth(wk, frames, 61, 97, tile_h=tile[1], dst=dst)
+        depth, mx = sharded_depth(wk, frames, 61, 97, tile_h=tile[1], dst=dst,
+                                  interleave=interleave)
         assert (depth is None) == (dst is not None and rank != dst)
         q.put((rank, None if depth is None else depth.numpy(), mx.numpy()))
         dist.barrier()
@@ -70,14 +79,17 @@ def _worker(rank, world, port, tile, q, dst=None):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,tile,dst", [(2, (1, 1), None), (3, (1, 1), 0), (2, (5, 5), 1)])
-def test_sharded_equals_single_process(world, tile, dst):
+@pytest.mark.parametrize("world,tile,dst,interleave", [(2, (1, 1), None, 0), (3, (1, 1), 0, 0),
+                                                       (2, (5, 5), 1, 0), (3, (1, 1), 0, 8),
+                                                       (2, (2, 2), None, 4)])
+def test_sharded_equals_single_process(world, tile, dst, interleave):
     from oracle import oracle as O
     from stepth_amd import synth
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, tile, q, dst)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, tile, q, dst, interleave))
+             for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=180) for _ in range(world)]
