@@ -35,9 +35,12 @@ struct DevBuf {
 
 } // namespace
 
-// words: [0] max, [1] host max staged for normalise_rows, [2] pending count, then from word 32
-// on the kParts run counters of ring_search_kernel
-constexpr size_t kWordsBytes = (32 + kParts * kPartStride) * 4;
+// words: [0..31] max per frame of a batch (a single call uses [0]), [32] host max staged for
+// normalise_rows, [33] pending count, then from word 64 on the kParts run counters of
+// ring_search_kernel
+constexpr uint32_t kWordHostMax = 32, kWordPending = 33, kWordCounters = 64;
+constexpr size_t kWordsBytes = (kWordCounters + kParts * kPartStride) * 4;
+static_assert(kMaxBatch <= 32, "per-frame max words");
 
 struct stepth_engine {
     int device = 0;
@@ -49,7 +52,7 @@ struct stepth_engine {
     DevBuf stage_main, stage_add, stage_out, stage_groups;
     DevBuf queries, raw, aux32, aux_pos, aux_found, pending, pending_rec, pending_key;
     DevBuf sad_left, sad_right, gauss_tmp, gauss_io;
-    uint32_t *words = nullptr; // [0] max, [1] host max staged for normalise_rows, [2] pending count, [3] next pending run
+    uint32_t *words = nullptr; // layout: kWord* above
     unsigned long long *stats = nullptr; // [ring0_hits, probes]
     DevBuf spiral;                       // block-spiral table + per-chunk complete rings
     uint32_t spiral_chunks = 0;
@@ -179,30 +182,47 @@ struct KernelTimer { // brackets the dominant kernel with events when timing is 
 // RGB8 additional image -> tiled cells T + block bounds BB (src/depth_image.rs:96-100)
 // Also clears the engine's words (max, pending count, run counters) for the kernels that
 // follow: one launch less than a memset.
-int pack_additional(stepth_engine *e, const uint8_t *d_add, size_t stride, uint32_t wa,
-                    uint32_t ha, uint32_t &bw, uint32_t &bh, uint32_t row_lo = 0,
-                    uint32_t row_hi = 0xFFFFFFFFu)
+int pack_additional(stepth_engine *e, uint32_t n_frames, const uint8_t *const *d_adds,
+                    size_t stride, uint32_t wa, uint32_t ha, uint32_t &bw, uint32_t &bh,
+                    uint32_t row_lo = 0, uint32_t row_hi = 0xFFFFFFFFu)
 {
     bw = (wa + 7u) / 8u;
     bh = (ha + 7u) / 8u;
     const size_t nblk = (size_t)bw * bh;
-    if (nblk * 64 > 0x3FFFFFFFull) // kernels index cells with 32-bit byte offsets
-        return fail(e, STEPTH_ERR_BAD_ARG, "additional image %ux%u exceeds 2^30 cells", wa, ha);
-    TRY(reserve(e, e->T, nblk * 64 * 4));
-    TRY(reserve(e, e->BB, nblk * 8));
+    if (nblk * 64 * n_frames > 0x3FFFFFFFull) // kernels index cells with 32-bit byte offsets
+        return fail(e, STEPTH_ERR_BAD_ARG, "additional image %ux%u x %u frames exceeds 2^30 cells",
+                    wa, ha, n_frames);
+    const uint32_t sbw = (bw + 7u) / 8u, sbh = (bh + 7u) / 8u;
+    TRY(reserve(e, e->T, nblk * 64 * 4 * n_frames));
+    TRY(reserve(e, e->BB, nblk * 8 * n_frames));
+    TRY(reserve(e, e->SB, (size_t)sbw * sbh * 8 * n_frames));
     // only the cell rows [row_lo,row_hi) can be reached by the searches of this call
     row_hi = std::min(row_hi, ha);
     row_lo = std::min(row_lo, row_hi);
     const uint32_t by0 = row_lo / 8u, by1 = std::max((row_hi + 7u) / 8u, by0 + 1u);
-    PackArgs pa{d_add, stride, wa, ha, bw, bh, (uint32_t *)e->T.p, (uint2 *)e->BB.p, by0,
-                std::min(by1, bh) - by0, e->words, (uint32_t)(kWordsBytes / 4)};
-    hipLaunchKernelGGL(pack_additional_kernel, dim3((bw * pa.nby + 3u) / 4u), dim3(256), 0,
-                       e->stream, pa);
-    const uint32_t sbw = (bw + 7u) / 8u, sbh = (bh + 7u) / 8u;
-    TRY(reserve(e, e->SB, (size_t)sbw * sbh * 8));
+    PackArgs pa{};
+    for (uint32_t f = 0; f < n_frames; ++f)
+        pa.src[f] = d_adds[f];
+    pa.stride = stride;
+    pa.wa = wa;
+    pa.ha = ha;
+    pa.bw = bw;
+    pa.bh = bh;
+    pa.T = (uint32_t *)e->T.p;
+    pa.BB = (uint2 *)e->BB.p;
+    pa.by0 = by0;
+    pa.nby = std::min(by1, bh) - by0;
+    pa.zero = e->words;
+    pa.n_zero = (uint32_t)(kWordsBytes / 4);
+    pa.t_stride = (uint32_t)(nblk * 64);
+    pa.bb_stride = (uint32_t)nblk;
+    hipLaunchKernelGGL(pack_additional_kernel, dim3((bw * pa.nby + 3u) / 4u, n_frames), dim3(256),
+                       0, e->stream, pa);
     SuperArgs sa{(const uint2 *)e->BB.p, bw, bh, sbw, sbh, (uint2 *)e->SB.p, by0 / 8u,
-                 (by0 + pa.nby + 7u) / 8u - by0 / 8u, by0, by0 + pa.nby};
-    hipLaunchKernelGGL(pack_super_kernel, dim3((sbw * sa.nsby + 3u) / 4u), dim3(256), 0, e->stream, sa);
+                 (by0 + pa.nby + 7u) / 8u - by0 / 8u, by0, by0 + pa.nby, (uint32_t)nblk,
+                 sbw * sbh};
+    hipLaunchKernelGGL(pack_super_kernel, dim3((sbw * sa.nsby + 3u) / 4u, n_frames), dim3(256), 0,
+                       e->stream, sa);
     HIP_TRY(e, hipGetLastError());
     return STEPTH_OK;
 }
@@ -233,7 +253,8 @@ int ensure_spiral(stepth_engine *e, uint32_t max_steps, uint32_t wa, uint32_t ha
     return STEPTH_OK;
 }
 
-int launch_ring(stepth_engine *e, RingArgs &ra, int qmode)
+// ra.n = queries per frame; n_frames > 1 only for QMODE 0 (one query per pixel)
+int launch_ring(stepth_engine *e, RingArgs &ra, int qmode, uint32_t n_frames = 1)
 {
     if (ra.n == 0)
         return STEPTH_OK;
@@ -256,14 +277,18 @@ int launch_ring(stepth_engine *e, RingArgs &ra, int qmode)
     }
     ra.spiral = (const uint32_t *)e->spiral.p;
     ra.spiral_done = ra.spiral + (size_t)e->spiral_chunks * 64;
-    TRY(reserve(e, e->pending, (size_t)ra.n * 4));
+    const size_t n_all = (size_t)ra.n * n_frames;
+    TRY(reserve(e, e->pending, n_all * 4));
     ra.pending = (uint32_t *)e->pending.p;
-    TRY(reserve(e, e->pending_rec, (size_t)ra.n * sizeof(Query)));
+    TRY(reserve(e, e->pending_rec, n_all * sizeof(Query)));
     ra.pending_rec = (Query *)e->pending_rec.p;
-    ra.pending_count = e->words + 2;
-    ra.pending_next = e->words + 32;
+    ra.pending_count = e->words + kWordPending;
+    ra.pending_next = e->words + kWordCounters;
     ra.stats = e->stats_enabled ? e->stats : nullptr;
-    TRY(reserve(e, e->pending_key, (size_t)ra.n * 4));
+    TRY(reserve(e, e->pending_key, n_all * 4));
+    const uint32_t nblk = ra.bw * ra.bh;
+    ra.t_stride = nblk * 64u;
+    ra.raw_stride = (uint32_t)((ra.n + 3u) & ~3u);
 
     SearchArgs sa{};
     sa.T = ra.T;
@@ -283,6 +308,9 @@ int launch_ring(stepth_engine *e, RingArgs &ra, int qmode)
     sa.sbw = ra.sbw;
     sa.max_steps = ra.max_steps;
     sa.pos_bits = ra.pos_bits;
+    sa.t_stride = ra.t_stride;
+    sa.bb_stride = nblk;
+    sa.sb_stride = ra.sbw * ra.sbh;
 
     FinishArgs fa{};
     fa.pending = ra.pending;
@@ -295,20 +323,21 @@ int launch_ring(stepth_engine *e, RingArgs &ra, int qmode)
     fa.pos = ra.pos;
     fa.found = ra.found;
     fa.max_word = ra.max_word;
+    fa.raw_stride = ra.raw_stride;
 
     // search waves pull runs of queries from counters, so any grid works; 8 workgroups of 4
     // waves per CU is the most that can be resident
-    const uint32_t search_blocks = std::min<uint32_t>(2048u, (ra.n + 63u) / 64u);
-    const uint32_t finish_blocks = std::min<uint32_t>(2048u, (ra.n + 255u) / 256u);
+    const uint32_t search_blocks = (uint32_t)std::min<size_t>(2048u, (n_all + 63u) / 64u);
+    const uint32_t finish_blocks = (uint32_t)std::min<size_t>(2048u, (n_all + 255u) / 256u);
     // block-rings a search can reach; the near + superblock scheme covers 33 of them
     const bool far_search =
         ((std::min(ra.max_steps, std::max(ra.wa, ra.ha)) + 6u) >> 3) > kSpiralRings;
     const bool st = e->stats_enabled;
     if (qmode == 0) {
         if (st)
-            hipLaunchKernelGGL((ring0_kernel<0, true>), dim3(blocks), dim3(256), 0, e->stream, ra);
+            hipLaunchKernelGGL((ring0_kernel<0, true>), dim3(blocks, n_frames), dim3(256), 0, e->stream, ra);
         else
-            hipLaunchKernelGGL((ring0_kernel<0, false>), dim3(blocks), dim3(256), 0, e->stream, ra);
+            hipLaunchKernelGGL((ring0_kernel<0, false>), dim3(blocks, n_frames), dim3(256), 0, e->stream, ra);
     } else {
         if (st)
             hipLaunchKernelGGL((ring0_kernel<1, true>), dim3(blocks), dim3(256), 0, e->stream, ra);
@@ -606,7 +635,7 @@ int stepth_depth_from_additional(stepth_engine *e, const stepth_image *main_im,
             pa.max_out = async ? max_out : nullptr;
             max_published = async && max_out;
             pa.identity = raw_only;
-            pa.out = d_out;
+            pa.out[0] = d_out;
             pa.ostride = os;
             pa.w = W;
             pa.h = H;
@@ -632,7 +661,7 @@ int stepth_depth_from_additional(stepth_engine *e, const stepth_image *main_im,
                 lo = c_lo > reach ? c_lo - reach : 0u;
                 hi = c_hi + reach + 1u;
             }
-            TRY(pack_additional(e, d_add, as, add_im->width, add_im->height, bw, bh, lo, hi));
+            TRY(pack_additional(e, 1, &d_add, as, add_im->width, add_im->height, bw, bh, lo, hi));
         }
 
         RingArgs ra{};
@@ -653,7 +682,7 @@ int stepth_depth_from_additional(stepth_engine *e, const stepth_image *main_im,
         pa.max_word = e->words;
         pa.max_out = async ? max_out : nullptr;
         pa.identity = raw_only;
-        pa.out = d_out;
+        pa.out[0] = d_out;
         pa.ostride = os;
         pa.w = W;
         pa.h = H;
@@ -706,7 +735,7 @@ int stepth_depth_from_additional(stepth_engine *e, const stepth_image *main_im,
             pa.tile_h = p.tile_h;
             pa.gx = gx;
             if (p.tile_w == 1 && p.tile_h == 1) {
-                ra.main_px = d_main;
+                ra.main_px[0] = d_main;
                 ra.mstride = ms;
                 ra.mch = main_im->channels;
                 ra.w = W;
@@ -834,8 +863,9 @@ int stepth_normalise_rows_pattern(stepth_engine *e, const stepth_image *rows, ui
             HIP_TRY(e, hipMemcpyAsync(&mx_host, max_ptr, 4, hipMemcpyDeviceToHost, e->stream));
     } else {
         mx_host = *max_ptr;
-        HIP_TRY(e, hipMemcpyAsync(e->words + 1, &mx_host, 4, hipMemcpyHostToDevice, e->stream));
-        d_max = e->words + 1;
+        HIP_TRY(e, hipMemcpyAsync(e->words + kWordHostMax, &mx_host, 4, hipMemcpyHostToDevice,
+                                  e->stream));
+        d_max = e->words + kWordHostMax;
     }
     if (row_block && (row_mod == 0 || row_rem >= row_mod))
         return fail(e, STEPTH_ERR_BAD_ARG, "row pattern: row_rem must be < row_mod");
@@ -932,7 +962,7 @@ int stepth_distance_dot_array_batch(stepth_engine *e, const stepth_image *array,
     size_t as = 0;
     TRY(to_device(e, *array, e->stage_add, d_add, as));
     uint32_t bw = 0, bh = 0;
-    TRY(pack_additional(e, d_add, as, array->width, array->height, bw, bh));
+    TRY(pack_additional(e, 1, &d_add, as, array->width, array->height, bw, bh));
 
     std::vector<Query> qs(n);
     for (size_t i = 0; i < n; ++i) {

@@ -23,11 +23,12 @@ namespace stepth {
 //
 // with bw = ceil(Wa/8), bh = ceil(Ha/8).  One wave packs one block.
 // ---------------------------------------------------------------------------------------
+constexpr int kMaxBatch = 32; // frames one set of launches can carry (blockIdx.y / record bits)
 constexpr int kBlk = 8;       // block side
 constexpr int kBlkShift = 3;
 
 struct PackArgs {
-    const uint8_t *src;
+    const uint8_t *src[kMaxBatch]; // one additional image per frame (blockIdx.y)
     size_t stride;
     uint32_t wa, ha;
     uint32_t bw, bh;
@@ -36,6 +37,7 @@ struct PackArgs {
     uint32_t by0, nby; // block rows to pack (a row strip only reaches part of the image)
     uint32_t *zero;    // words to clear for the kernels that follow (max, counters) ...
     uint32_t n_zero;   // ... instead of a separate memset launch
+    uint32_t t_stride, bb_stride; // per-frame strides of T (dwords) and BB (uint2)
 };
 
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
@@ -56,8 +58,8 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
 
 __global__ __launch_bounds__(256) void pack_additional_kernel(PackArgs a)
 {
-    const uint32_t lane = threadIdx.x & 63u;
-    if (blockIdx.x == 0)
+    const uint32_t lane = threadIdx.x & 63u, f = blockIdx.y;
+    if (blockIdx.x == 0 && f == 0)
         for (uint32_t i = threadIdx.x; i < a.n_zero; i += blockDim.x)
             a.zero[i] = 0u;
     const uint32_t idx = blockIdx.x * 4u + (threadIdx.x >> 6);
@@ -69,20 +71,21 @@ __global__ __launch_bounds__(256) void pack_additional_kernel(PackArgs a)
     uint32_t cell = kNoCell;
     uint32_t mn[3] = {255u, 255u, 255u}, mx[3] = {0u, 0u, 0u};
     if (x < a.wa && y < a.ha) {
-        const uint8_t *p = a.src + (size_t)y * a.stride + (size_t)x * 3;
+        const uint8_t *p = a.src[f] + (size_t)y * a.stride + (size_t)x * 3;
         mn[0] = mx[0] = p[0];
         mn[1] = mx[1] = p[1];
         mn[2] = mx[2] = p[2];
         cell = pack_cell(p[0], p[1], p[2]);
     }
-    a.T[(size_t)blk * 64u + lane] = cell;
+    a.T[(size_t)f * a.t_stride + (size_t)blk * 64u + lane] = cell;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         mn[c] = wave_min_u32(mn[c]);
         mx[c] = wave_max_u32(mx[c]);
     }
     if (lane == 0)
-        a.BB[blk] = make_uint2(pack_cell(mx[0], mx[1], mx[2]), pack_cell(mn[0], mn[1], mn[2]));
+        a.BB[(size_t)f * a.bb_stride + blk] =
+            make_uint2(pack_cell(mx[0], mx[1], mx[2]), pack_cell(mn[0], mn[1], mn[2]));
 }
 
 // Superblock bounds: one wave folds the bounds of 8x8 blocks (64x64 cells) into SB.
@@ -92,6 +95,7 @@ struct SuperArgs {
     uint2 *SB;
     uint32_t sby0, nsby; // superblock rows to fold, and the block rows that are valid: blocks
     uint32_t by0, by1;   // outside [by0,by1) hold stale bounds and are left out
+    uint32_t bb_stride, sb_stride; // per-frame strides (blockIdx.y = frame)
 };
 
 __global__ __launch_bounds__(256) void pack_super_kernel(SuperArgs a)
@@ -104,7 +108,7 @@ __global__ __launch_bounds__(256) void pack_super_kernel(SuperArgs a)
     const uint32_t bx = (sb % a.sbw) * 8u + (lane & 7u), by = (sb / a.sbw) * 8u + (lane >> 3);
     uint32_t mn[3] = {255u, 255u, 255u}, mx[3] = {0u, 0u, 0u};
     if (bx < a.bw && by >= a.by0 && by < a.by1) {
-        const uint2 bb = a.BB[(size_t)by * a.bw + bx];
+        const uint2 bb = a.BB[(size_t)blockIdx.y * a.bb_stride + (size_t)by * a.bw + bx];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             mx[c] = (bb.x >> (10 * c)) & 0xffu;
@@ -117,7 +121,8 @@ __global__ __launch_bounds__(256) void pack_super_kernel(SuperArgs a)
         mx[c] = wave_max_u32(mx[c]);
     }
     if (lane == 0)
-        a.SB[sb] = make_uint2(pack_cell(mx[0], mx[1], mx[2]), pack_cell(mn[0], mn[1], mn[2]));
+        a.SB[(size_t)blockIdx.y * a.sb_stride + sb] =
+            make_uint2(pack_cell(mx[0], mx[1], mx[2]), pack_cell(mn[0], mn[1], mn[2]));
 }
 
 // Rows a call owns inside [row_begin,row_end): all of them (block == 0), or every mod-th block
@@ -219,7 +224,7 @@ __global__ __launch_bounds__(256) void prep_list_kernel(PrepArgs a)
 // is the matching cell with the smallest key, so cells may be examined in ANY order and most
 // of them need not be examined at all.
 //
-//   ring0_kernel   dense, one lane per query: tests the centre cell (ring 0) -- on natural
+//   ring0_kernel   dense, one lane per query (blockIdx.y = frame of a batch): tests the centre cell (ring 0) -- on natural
 //                  images a large share of the queries ends here -- writes the result 0 for
 //                  every query and compacts the survivors into `pending` (one wave-aggregated
 //                  atomic per wave).
@@ -248,8 +253,9 @@ struct RingArgs {
     const uint2 *BB;
     const uint2 *SB; // superblock (8x8 blocks) bounds, [sbh][sbw]
     uint32_t wa, ha, bw, bh, sbw, sbh;
-    // QMODE 0: one query per main pixel (uniform 1x1 tiles), read straight from the image
-    const uint8_t *main_px;
+    // QMODE 0: one query per main pixel (uniform 1x1 tiles), read straight from the image;
+    // one image per frame (blockIdx.y)
+    const uint8_t *main_px[kMaxBatch];
     size_t mstride;
     uint32_t mch, w, row0, row1;
     uint32_t ntx, ty0, n_slots; // 2x2 tiles of the strip: columns, first tile row, slots
@@ -273,6 +279,7 @@ struct RingArgs {
     Query *pending_rec;
     uint32_t *pending_count;     // 1 word, zeroed before ring0_kernel
     uint32_t *pending_next;      // kParts counters kPartStride words apart, zeroed: runs handed out
+    uint32_t t_stride, raw_stride; // per-frame strides of T (dwords) and raw (bytes)
 };
 
 constexpr uint32_t kNoKey = 0xFFFFFFFFu;
@@ -366,7 +373,7 @@ STEPTH_HD uint32_t rings_done(uint32_t done) { return (isqrt_floor(done) - 1u) >
 // search centre sit next to each other in the pending list and ring_search_kernel can serve
 // them together.  Returns false for slots outside the image / strip.
 template <int QMODE>
-__device__ __forceinline__ bool load_query(const RingArgs &a, uint32_t slot, uint32_t &q,
+__device__ __forceinline__ bool load_query(const RingArgs &a, uint32_t f, uint32_t slot, uint32_t &q,
                                            uint32_t &cx, uint32_t &cy, uint32_t &lo,
                                            uint32_t &hi)
 {
@@ -388,7 +395,7 @@ __device__ __forceinline__ bool load_query(const RingArgs &a, uint32_t slot, uin
         if (slot >= a.n_slots || x >= a.w || y < y_lo || y >= y_hi)
             return false;
         q = (y - a.row0) * a.w + x;
-        const uint8_t *p = a.main_px + (size_t)y * a.mstride + (size_t)x * a.mch;
+        const uint8_t *p = a.main_px[f] + (size_t)y * a.mstride + (size_t)x * a.mch;
         const uint8_t v[3] = {p[0], p[1], p[2]};
         cx = tx;
         cy = ty;
@@ -418,6 +425,7 @@ __global__ __launch_bounds__(256) void ring0_kernel(RingArgs a)
     __shared__ uint32_t s_wave_total[4];
     __shared__ uint32_t s_base;
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t f = blockIdx.y; // frame
     Query rec[kRing0Iters];
     uint32_t qid[kRing0Iters];
     uint32_t pend_bits = 0, n_mine = 0;
@@ -426,18 +434,18 @@ __global__ __launch_bounds__(256) void ring0_kernel(RingArgs a)
     for (uint32_t it = 0; it < kRing0Iters; ++it) {
         const uint32_t slot = (blockIdx.x * kRing0Iters + it) * 256u + threadIdx.x;
         uint32_t q = 0, cx = ~0u, cy = ~0u, lo = 0, hi = 0;
-        const bool valid = load_query<QMODE>(a, slot, q, cx, cy, lo, hi);
+        const bool valid = load_query<QMODE>(a, f, slot, q, cx, cy, lo, hi);
         qid[it] = q;
         const bool inb = valid && cx < a.wa && cy < a.ha && a.max_steps > 0;
         bool fnd = false, pending = false;
         if (inb) {
             const uint32_t blk = (cy >> kBlkShift) * a.bw + (cx >> kBlkShift);
-            const uint32_t c = a.T[blk * 64u + ((cy & 7u) << 3) + (cx & 7u)];
+            const uint32_t c = a.T[(size_t)f * a.t_stride + blk * 64u + ((cy & 7u) << 3) + (cx & 7u)];
             fnd = cell_in_box(c, lo, hi);
             pending = !fnd && a.max_steps > 1;
         }
         if (valid) { // a ring-0 hit has distance 0; None is 0 too (depth_image.rs:118-121)
-            a.raw[q] = 0;
+            a.raw[(size_t)f * a.raw_stride + q] = 0;
             if (a.raw32)
                 a.raw32[q] = 0;
             if (a.pos) {
@@ -447,7 +455,7 @@ __global__ __launch_bounds__(256) void ring0_kernel(RingArgs a)
             if (a.found)
                 a.found[q] = fnd ? 1 : 0;
         }
-        rec[it] = Query{cx, cy, lo, hi};
+        rec[it] = Query{cx, cy | (f << 16), lo, hi}; // pending records carry their frame
         const unsigned long long pm = __ballot(pending);
         if (pending)
             pend_bits |= 1u << it;
@@ -502,6 +510,7 @@ struct SearchArgs {
     const uint32_t *spiral_done;
     unsigned long long *stats;
     uint32_t wa, ha, bw, bh, sbw, max_steps, pos_bits;
+    uint32_t t_stride, bb_stride, sb_stride; // per-frame strides; a record's frame = cy >> 16
 };
 
 __device__ __forceinline__ unsigned long long ballot(bool p)
@@ -582,7 +591,11 @@ __global__ __launch_bounds__(256) STEPTH_SEARCH_ATTR void ring_search_kernel(Sea
             const unsigned long long later = (starts >> r) >> 1; // group starts after r
             const uint32_t till = later ? (uint32_t)__ffsll(later) : run_len - r;
             const uint32_t M = min(min(till, run_len - r), 4u); // members r .. r+M-1
-            const uint32_t qx = bcast(rec.cx, (int)r), qy = bcast(rec.cy, (int)r);
+            const uint32_t qx = bcast(rec.cx, (int)r), qyf = bcast(rec.cy, (int)r);
+            const uint32_t qy = qyf & 0xffffu, frame = qyf >> 16;
+            // frame offsets stay 32-bit indices (the whole batch holds < 2^30 cells)
+            const uint32_t tf = frame * a.t_stride, bf = frame * a.bb_stride;
+            const uint32_t sf = frame * a.sb_stride;
             const uint32_t smax = max(max(qx, a.wa - 1u - qx), max(qy, a.ha - 1u - qy));
             const uint32_t s_end = min(a.max_steps, smax + 1u); // rings 0..s_end-1 are searched
             const int cbx = (int)(qx >> kBlkShift), cby = (int)(qy >> kBlkShift);
@@ -688,8 +701,8 @@ __global__ __launch_bounds__(256) STEPTH_SEARCH_ATTR void ring_search_kernel(Sea
                     const uint32_t blk0 = (uint32_t)(cby + j0) * a.bw + (uint32_t)(cbx + i0);
                     const uint32_t blk1 = (uint32_t)(cby + j1) * a.bw + (uint32_t)(cbx + i1);
                     const uint32_t cell0 = cell_of(t0), cell1 = cell_of(t1);
-                    const uint32_t c0 = a.T[blk0 * 64u + cell0];
-                    const uint32_t c1 = a.T[blk1 * 64u + cell1];
+                    const uint32_t c0 = a.T[tf + blk0 * 64u + cell0];
+                    const uint32_t c1 = a.T[tf + blk1 * 64u + cell1];
                     bool changed = resolve(i0, j0, t0, d0, cell0, c0);
                     if (two)
                         changed |= resolve(i1, j1, t1, d1, cell1, c1);
@@ -717,7 +730,7 @@ __global__ __launch_bounds__(256) STEPTH_SEARCH_ATTR void ring_search_kernel(Sea
                     bool cand = u0 + lane < u_end && (uint32_t)bx < a.bw &&
                                 (uint32_t)by < a.bh && dmin < glimit;
                     if (cand)
-                        cand = wanted(a.BB[(uint32_t)by * a.bw + (uint32_t)bx], dmin);
+                        cand = wanted(a.BB[bf + (uint32_t)by * a.bw + (uint32_t)bx], dmin);
                     if constexpr (STATS) {
                         n_probe += 64ull;
                         ++n_near;
@@ -735,7 +748,7 @@ __global__ __launch_bounds__(256) STEPTH_SEARCH_ATTR void ring_search_kernel(Sea
                     const uint32_t dmin = block_dmin(nbi, nbj);
                     bool cand = (uint32_t)bx < a.bw && (uint32_t)by < a.bh && dmin < glimit;
                     if (cand)
-                        cand = wanted(a.BB[(uint32_t)by * a.bw + (uint32_t)bx], dmin);
+                        cand = wanted(a.BB[bf + (uint32_t)by * a.bw + (uint32_t)bx], dmin);
                     if constexpr (STATS) {
                         n_probe += 64ull;
                         ++n_near;
@@ -768,7 +781,7 @@ __global__ __launch_bounds__(256) STEPTH_SEARCH_ATTR void ring_search_kernel(Sea
                             const uint32_t dS =
                                 (uint32_t)max(max(max(ax, -63 - ax), max(ay, -63 - ay)), 0);
                             if (dS < glimit &&
-                                wanted(a.SB[(uint32_t)sy * a.sbw + (uint32_t)sx], dS))
+                                wanted(a.SB[sf + (uint32_t)sy * a.sbw + (uint32_t)sx], dS))
                                 skey[h] = (dS << 8) | (uint32_t)(ty * 16 + tx);
                         }
                         if (4 * (h + 1) >= nsy)
@@ -796,7 +809,7 @@ __global__ __launch_bounds__(256) STEPTH_SEARCH_ATTR void ring_search_kernel(Sea
                         bool cand = (uint32_t)bx < a.bw && (uint32_t)by < a.bh && dmin < glimit &&
                                     max(abs(bi), abs(bj)) > 3;
                         if (cand)
-                            cand = wanted(a.BB[(uint32_t)by * a.bw + (uint32_t)bx], dmin);
+                            cand = wanted(a.BB[bf + (uint32_t)by * a.bw + (uint32_t)bx], dmin);
                         if constexpr (STATS) {
                             n_probe += 64ull;
                             ++n_super;
@@ -836,43 +849,76 @@ struct FinishArgs {
     uint8_t *raw;
     uint32_t *raw32, *pos;
     uint8_t *found;
-    uint32_t *max_word;
+    uint32_t *max_word;  // one word per frame
+    uint32_t raw_stride; // bytes between the frames' raw maps
 };
 
 __global__ __launch_bounds__(256) void ring_finish_kernel(FinishArgs a)
 {
-    __shared__ uint32_t s_max;
-    if (threadIdx.x == 0)
-        s_max = 0;
-    __syncthreads();
+    // Same-address atomics cost ~11 ns each chip-wide: the max is folded per workgroup and
+    // carried across its iterations, flushed only when the frame changes (records are ordered
+    // by frame, so that is about once per workgroup).
+    __shared__ uint32_t s_f[4], s_m[4], s_mixed;
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const uint32_t count = *a.count;
-    uint32_t mx = 0;
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < count; i += gridDim.x * 256u) {
-        const uint32_t key = a.key[i];
-        if (key == kNoKey)
-            continue;
-        const uint32_t q = a.pending[i];
-        int dx, dy;
-        key_to_offset(key, a.pos_bits, dx, dy);
-        const uint32_t d = isqrt_floor((uint32_t)(dx * dx + dy * dy));
-        a.raw[q] = (uint8_t)(d & 0xffu);
-        mx = max(mx, d & 0xffu);
-        if (a.raw32)
-            a.raw32[q] = d;
-        if (a.pos) {
+    uint32_t cur_f = ~0u, cur_m = 0; // thread 0: frame and max carried so far
+    for (uint32_t i0 = blockIdx.x * 256u; i0 < count; i0 += gridDim.x * 256u) {
+        const uint32_t i = i0 + threadIdx.x;
+        uint32_t d8 = 0, frame = ~0u;
+        if (i < count) {
             const Query r = a.rec[i];
-            a.pos[2 * (size_t)q] = (uint32_t)((int)r.cx + dx);
-            a.pos[2 * (size_t)q + 1] = (uint32_t)((int)r.cy + dy);
+            frame = r.cy >> 16;
+            const uint32_t key = a.key[i];
+            if (key != kNoKey) {
+                const uint32_t q = a.pending[i];
+                int dx, dy;
+                key_to_offset(key, a.pos_bits, dx, dy);
+                const uint32_t d = isqrt_floor((uint32_t)(dx * dx + dy * dy));
+                d8 = d & 0xffu;
+                a.raw[(size_t)frame * a.raw_stride + q] = (uint8_t)d8;
+                if (a.raw32)
+                    a.raw32[q] = d;
+                if (a.pos) {
+                    a.pos[2 * (size_t)q] = (uint32_t)((int)r.cx + dx);
+                    a.pos[2 * (size_t)q + 1] = (uint32_t)((int)(r.cy & 0xffffu) + dy);
+                }
+                if (a.found)
+                    a.found[q] = 1;
+            }
         }
-        if (a.found)
-            a.found[q] = 1;
+        // lane 0 of a wave is its lowest record; records beyond `count` only follow valid ones
+        const uint32_t f0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)frame);
+        const bool wave_mixed = __builtin_amdgcn_ballot_w64(i < count && frame != f0) != 0;
+        const uint32_t m = wave_max_u32(d8);
+        if (threadIdx.x == 0)
+            s_mixed = 0;
+        __syncthreads();
+        if (lane == 0) {
+            s_f[wv] = f0;
+            s_m[wv] = m;
+            if (wave_mixed || (f0 != ~0u && f0 != (uint32_t)__builtin_amdgcn_readfirstlane(
+                                                       (int)a.rec[i0].cy) >> 16))
+                s_mixed = 1; // this workgroup's 256 records straddle a frame boundary
+        }
+        __syncthreads();
+        if (s_mixed) { // rare: every lane for itself
+            if (d8)
+                atomicMax(&a.max_word[frame], d8);
+        } else if (threadIdx.x == 0) {
+            const uint32_t f = s_f[0]; // wave 0 always holds valid records here
+            const uint32_t mm = max(max(s_m[0], s_m[1]), max(s_m[2], s_m[3]));
+            if (f != cur_f) {
+                if (cur_m)
+                    atomicMax(&a.max_word[cur_f], cur_m);
+                cur_f = f;
+                cur_m = 0;
+            }
+            cur_m = max(cur_m, mm);
+        }
+        __syncthreads();
     }
-    mx = wave_max_u32(mx);
-    if ((threadIdx.x & 63u) == 0 && mx)
-        atomicMax(&s_max, mx);
-    __syncthreads();
-    if (threadIdx.x == 0 && s_max)
-        atomicMax(a.max_word, s_max);
+    if (threadIdx.x == 0 && cur_m)
+        atomicMax(&a.max_word[cur_f], cur_m);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -896,7 +942,7 @@ struct PaintArgs {
     const uint32_t *max_word;
     uint32_t *max_out; // optional: the caller's copy of the max (device memory)
     int identity;
-    uint8_t *out; // [H][W], points at row 0 of the image
+    uint8_t *out[kMaxBatch]; // [H][W] per frame (blockIdx.y), row 0 of the image
     size_t ostride;
     uint32_t w, h;
     uint32_t row_begin, row_end;
@@ -904,13 +950,17 @@ struct PaintArgs {
     uint32_t tile_w, tile_h, gx; // uniform tiles
     const void *groups;          // or list
     uint32_t n;
+    uint32_t raw_stride; // bytes between the frames' raw maps
 };
 
 // uniform tiles (incl. 1x1): one thread per output pixel of the strip
 __global__ __launch_bounds__(256) void paint_tiles_kernel(PaintArgs a)
 {
     __shared__ uint8_t lut[256];
-    build_lut(lut, a.max_word, a.identity, a.max_out);
+    const uint32_t f = blockIdx.y;
+    build_lut(lut, a.max_word + f, a.identity, a.max_out ? a.max_out + f : nullptr);
+    const uint8_t *raw = a.raw + (size_t)f * a.raw_stride;
+    uint8_t *out = a.out[f];
     const uint32_t rows = a.row_end - a.row_begin;
     const size_t total = (size_t)rows * a.w;
     const uint32_t gy0 = a.row_begin / a.tile_h;
@@ -920,7 +970,7 @@ __global__ __launch_bounds__(256) void paint_tiles_kernel(PaintArgs a)
         if (!a.rp.owns(y))
             continue;
         const size_t g = (size_t)(y / a.tile_h - gy0) * a.gx + x / a.tile_w;
-        a.out[(size_t)y * a.ostride + x] = lut[a.raw[g]];
+        out[(size_t)y * a.ostride + x] = lut[raw[g]];
     }
 }
 
@@ -928,7 +978,10 @@ __global__ __launch_bounds__(256) void paint_tiles_kernel(PaintArgs a)
 __global__ __launch_bounds__(256) void paint_1x1_vec4_kernel(PaintArgs a)
 {
     __shared__ uint8_t lut[256];
-    build_lut(lut, a.max_word, a.identity, a.max_out);
+    const uint32_t f = blockIdx.y;
+    build_lut(lut, a.max_word + f, a.identity, a.max_out ? a.max_out + f : nullptr);
+    const uint8_t *raw = a.raw + (size_t)f * a.raw_stride;
+    uint8_t *out = a.out[f];
     const uint32_t rows = a.row_end - a.row_begin, w4 = a.w >> 2;
     const size_t total = (size_t)rows * w4;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -936,11 +989,11 @@ __global__ __launch_bounds__(256) void paint_1x1_vec4_kernel(PaintArgs a)
         const uint32_t r = (uint32_t)(i / w4), c = (uint32_t)(i % w4);
         if (!a.rp.owns(a.row_begin + r))
             continue;
-        const uint32_t v = reinterpret_cast<const uint32_t *>(a.raw)[i];
+        const uint32_t v = reinterpret_cast<const uint32_t *>(raw)[i];
         const uint32_t o = (uint32_t)lut[v & 0xff] | ((uint32_t)lut[(v >> 8) & 0xff] << 8) |
                            ((uint32_t)lut[(v >> 16) & 0xff] << 16) |
                            ((uint32_t)lut[v >> 24] << 24);
-        *reinterpret_cast<uint32_t *>(a.out + (size_t)(a.row_begin + r) * a.ostride + 4u * c) = o;
+        *reinterpret_cast<uint32_t *>(out + (size_t)(a.row_begin + r) * a.ostride + 4u * c) = o;
     }
 }
 
@@ -963,7 +1016,7 @@ __global__ __launch_bounds__(256) void paint_list_kernel(PaintArgs a)
     const size_t cells = (size_t)w * h;
     for (size_t i = lane; i < cells; i += 64u) {
         const uint32_t yy = r.y + (uint32_t)(i / w), xx = r.x + (uint32_t)(i % w);
-        a.out[(size_t)yy * a.ostride + xx] = v;
+        a.out[0][(size_t)yy * a.ostride + xx] = v;
     }
 }
 
