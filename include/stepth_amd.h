@@ -152,6 +152,23 @@ int stepth_depth_from_additional(stepth_engine *engine, const stepth_image *main
                                  uint32_t *max_out);
 
 /*
+ * The same path for a batch of frames in ONE set of kernel launches (the per-frame maxima stay
+ * separate: each frame is normalised by its own max, src/depth_image.rs:124-129).  A single
+ * small frame or row strip cannot fill the GPU -- the cost of a query varies by two orders of
+ * magnitude and one heavy query is a ~100 us critical path -- so callers with several frames
+ * in flight (video, row-strip sharding of many frames) should batch them.
+ *   - ring mode, uniform 1x1 tiles (one group per pixel), every frame the same sizes/strides,
+ *     all images in device memory; params (rows, row pattern, flags) apply to every frame;
+ *   - n_frames is not limited (the engine works through it in chunks of 32);
+ *   - max_out: n_frames words, device memory with STEPTH_FLAG_ASYNC, host memory otherwise
+ *     (synchronous calls return STEPTH_ERR_MAX_ZERO if ANY frame's max is 0).
+ */
+int stepth_depth_from_additional_batch(stepth_engine *engine, uint32_t n_frames,
+                                       const stepth_image *mains, const stepth_image *additionals,
+                                       const stepth_params *params, const stepth_image *depths,
+                                       uint32_t *max_out);
+
+/*
  * PASS 2 on a strip, src/depth_image.rs:125-129: data[r][c] = data[r][c]*255/max (u64
  * floor), in place.  `max` is read from `max_ptr` (`max_memory` = host or device) -- after
  * a cross-rank max reduction in the sharded flow.  max == 0 -> rows are zeroed and
@@ -165,6 +182,13 @@ int stepth_normalise_rows_pattern(stepth_engine *engine, const stepth_image *row
                                   uint32_t first_row, uint32_t row_block, uint32_t row_mod,
                                   uint32_t row_rem, const uint32_t *max_ptr,
                                   uint32_t max_memory, uint32_t flags);
+
+/* PASS 2 for a batch of equally shaped device images in one launch; `max_ptr` holds one word
+ * per frame (device memory). */
+int stepth_normalise_rows_batch(stepth_engine *engine, uint32_t n_frames,
+                                const stepth_image *rows, uint32_t first_row, uint32_t row_block,
+                                uint32_t row_mod, uint32_t row_rem, const uint32_t *max_ptr,
+                                uint32_t flags);
 
 /*
  * The tail alone, src/depth_image.rs:133-134: DynamicImage::resize(w, h, Gaussian) of a Luma8

@@ -73,11 +73,16 @@ SYMBOLS = {
     "stepth_depth_from_additional": (C.c_int, [C.c_void_p, _P(Image), _P(Image), _P(Params),
                                                C.c_void_p, C.c_size_t, C.c_uint32, _P(Image),
                                                C.c_void_p]),
+    "stepth_depth_from_additional_batch": (C.c_int, [C.c_void_p, C.c_uint32, _P(Image), _P(Image),
+                                                     _P(Params), _P(Image), C.c_void_p]),
     "stepth_normalise_rows": (C.c_int, [C.c_void_p, _P(Image), C.c_void_p, C.c_uint32,
                                         C.c_uint32]),
     "stepth_normalise_rows_pattern": (C.c_int, [C.c_void_p, _P(Image), C.c_uint32, C.c_uint32,
                                                 C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32,
                                                 C.c_uint32]),
+    "stepth_normalise_rows_batch": (C.c_int, [C.c_void_p, C.c_uint32, _P(Image), C.c_uint32,
+                                              C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p,
+                                              C.c_uint32]),
     "stepth_gaussian_same_size": (C.c_int, [C.c_void_p, _P(Image), _P(Image), C.c_uint32]),
     "stepth_distance_dot_array_batch": (C.c_int, [C.c_void_p, _P(Image), C.c_void_p, C.c_void_p,
                                                   C.c_size_t, C.c_uint32, C.c_void_p,

@@ -328,7 +328,7 @@ int launch_ring(stepth_engine *e, RingArgs &ra, int qmode, uint32_t n_frames = 1
     // search waves pull runs of queries from counters, so any grid works; 8 workgroups of 4
     // waves per CU is the most that can be resident
     const uint32_t search_blocks = (uint32_t)std::min<size_t>(2048u, (n_all + 63u) / 64u);
-    const uint32_t finish_blocks = (uint32_t)std::min<size_t>(2048u, (n_all + 255u) / 256u);
+    const uint32_t finish_blocks = (uint32_t)std::min<size_t>(512u, (n_all + 255u) / 256u);
     // block-rings a search can reach; the near + superblock scheme covers 33 of them
     const bool far_search =
         ((std::min(ra.max_steps, std::max(ra.wa, ra.ha)) + 6u) >> 3) > kSpiralRings;
@@ -842,6 +842,152 @@ int stepth_depth_from_additional(stepth_engine *e, const stepth_image *main_im,
     return STEPTH_OK;
 }
 
+int stepth_depth_from_additional_batch(stepth_engine *e, uint32_t n_frames,
+                                       const stepth_image *mains, const stepth_image *adds,
+                                       const stepth_params *pp, const stepth_image *depths,
+                                       uint32_t *max_out)
+{
+    if (!e)
+        return STEPTH_ERR_BAD_ARG;
+    if (!pp || pp->struct_size != sizeof(stepth_params))
+        return fail(e, STEPTH_ERR_BAD_ARG, "params null or struct_size mismatch");
+    if (n_frames == 0 || !mains || !adds || !depths)
+        return fail(e, STEPTH_ERR_BAD_ARG, "empty batch or null image arrays");
+    const stepth_params p = *pp;
+    if (p.mode != STEPTH_MODE_RING_FIRST_HIT || p.tile_w != 1 || p.tile_h != 1 ||
+        (p.flags & STEPTH_FLAG_GAUSSIAN_TAIL))
+        return fail(e, STEPTH_ERR_BAD_ARG,
+                    "batch: ring mode with 1x1 tiles only, no Gaussian tail");
+    for (uint32_t f = 0; f < n_frames; ++f) {
+        TRY(check_image(e, &mains[f], "main", 3, 4));
+        TRY(check_image(e, &adds[f], "additional", 3, 3));
+        TRY(check_image(e, &depths[f], "depth", 1, 1));
+        if (mains[f].memory != STEPTH_MEM_DEVICE || adds[f].memory != STEPTH_MEM_DEVICE ||
+            depths[f].memory != STEPTH_MEM_DEVICE)
+            return fail(e, STEPTH_ERR_BAD_ARG, "batch: images must be device memory");
+        if (mains[f].width != mains[0].width || mains[f].height != mains[0].height ||
+            mains[f].channels != mains[0].channels || mains[f].stride != mains[0].stride ||
+            adds[f].width != adds[0].width || adds[f].height != adds[0].height ||
+            adds[f].stride != adds[0].stride || depths[f].stride != depths[0].stride)
+            return fail(e, STEPTH_ERR_BAD_ARG, "batch: frame %u differs in size or stride", f);
+        if (depths[f].width != mains[0].width || depths[f].height != mains[0].height)
+            return fail(e, STEPTH_ERR_SIZE_MISMATCH, "Sizes don't match");
+    }
+    const uint32_t W = mains[0].width, H = mains[0].height;
+    const bool async = p.flags & STEPTH_FLAG_ASYNC, raw_only = p.flags & STEPTH_FLAG_RAW_ONLY;
+    uint32_t row0 = p.row_begin, row1 = p.row_end;
+    if (row0 == 0 && row1 == 0)
+        row1 = H;
+    if (row0 >= row1 || row1 > H)
+        return fail(e, STEPTH_ERR_BAD_ARG, "row strip [%u,%u) outside 0..%u", row0, row1, H);
+    RowPattern rp{0u, 1u, 0u};
+    if (p.row_block) {
+        if ((p.row_block & 1u) || p.row_mod == 0 || p.row_rem >= p.row_mod)
+            return fail(e, STEPTH_ERR_BAD_ARG, "row pattern: even row_block, row_rem < row_mod");
+        rp = RowPattern{p.row_block, p.row_mod, p.row_rem};
+    }
+    HIP_TRY(e, hipSetDevice(e->device));
+    const uint32_t rows = row1 - row0;
+    bool any_zero = false;
+
+    for (uint32_t f0 = 0; f0 < n_frames; f0 += kMaxBatch) {
+        const uint32_t nf = std::min<uint32_t>(kMaxBatch, n_frames - f0);
+        const uint8_t *d_adds[kMaxBatch];
+        for (uint32_t f = 0; f < nf; ++f)
+            d_adds[f] = static_cast<const uint8_t *>(adds[f0 + f].data);
+        uint32_t bw = 0, bh = 0, lo = 0, hi = 0xFFFFFFFFu;
+        if (p.max_steps < 0x40000000u) { // rows of the additional image the searches can reach
+            const uint32_t reach = p.max_steps ? p.max_steps - 1u : 0u;
+            lo = row0 / 2u > reach ? row0 / 2u - reach : 0u;
+            hi = (row1 + 1u) / 2u + reach + 1u;
+        }
+        TRY(pack_additional(e, nf, d_adds, adds[0].stride, adds[0].width, adds[0].height, bw, bh,
+                            lo, hi));
+
+        RingArgs ra{};
+        ra.T = (const uint32_t *)e->T.p;
+        ra.BB = (const uint2 *)e->BB.p;
+        ra.SB = (const uint2 *)e->SB.p;
+        ra.sbw = (bw + 7u) / 8u;
+        ra.sbh = (bh + 7u) / 8u;
+        ra.wa = adds[0].width;
+        ra.ha = adds[0].height;
+        ra.bw = bw;
+        ra.bh = bh;
+        ra.max_steps = p.max_steps;
+        memcpy(ra.prec, p.precision, 3);
+        ra.max_word = e->words;
+        for (uint32_t f = 0; f < nf; ++f)
+            ra.main_px[f] = static_cast<const uint8_t *>(mains[f0 + f].data);
+        ra.mstride = mains[0].stride;
+        ra.mch = mains[0].channels;
+        ra.w = W;
+        ra.row0 = row0;
+        ra.row1 = row1;
+        ra.ntx = (W >> 1) + 1u;
+        ra.ty0 = (row0 + 1u) >> 1;
+        ra.n_slots = ra.ntx * ((row1 >> 1) - ra.ty0 + 1u) * 4u;
+        ra.rp = rp;
+        if (rp.block) {
+            const uint32_t nb_all = (H + rp.block - 1u) / rp.block;
+            const uint32_t nb = nb_all > rp.rem ? (nb_all - rp.rem + rp.mod - 1u) / rp.mod : 0u;
+            ra.n_slots = ra.ntx * nb * (rp.block / 2u + 1u) * 4u;
+        }
+        ra.n = W * rows;
+        const size_t raw_stride = ((size_t)ra.n + 3u) & ~(size_t)3u;
+        TRY(reserve(e, e->raw, raw_stride * nf));
+        ra.raw = static_cast<uint8_t *>(e->raw.p);
+        if (e->stats_enabled) {
+            HIP_TRY(e, hipMemsetAsync(e->stats, 0, 64, e->stream));
+            e->stats_groups = (uint64_t)ra.n * nf;
+        }
+        if (ra.n_slots)
+            TRY(launch_ring(e, ra, 0, nf));
+
+        PaintArgs pa{};
+        pa.raw = ra.raw;
+        pa.raw_stride = (uint32_t)raw_stride;
+        pa.max_word = e->words;
+        pa.max_out = (async && max_out) ? max_out + f0 : nullptr;
+        pa.identity = raw_only;
+        for (uint32_t f = 0; f < nf; ++f)
+            pa.out[f] = static_cast<uint8_t *>(const_cast<void *>(depths[f0 + f].data));
+        pa.ostride = depths[0].stride;
+        pa.w = W;
+        pa.h = H;
+        pa.row_begin = row0;
+        pa.row_end = row1;
+        pa.rp = rp;
+        pa.tile_w = pa.tile_h = 1;
+        pa.gx = W;
+        pa.n = ra.n;
+        bool vec4 = (W & 3u) == 0 && (pa.ostride & 3u) == 0;
+        for (uint32_t f = 0; f < nf; ++f)
+            vec4 = vec4 && (reinterpret_cast<uintptr_t>(pa.out[f]) & 3u) == 0;
+        const size_t total = (size_t)rows * (vec4 ? W / 4 : W);
+        const dim3 grid((uint32_t)std::min<size_t>((total + 255) / 256, 1024), nf);
+        if (vec4)
+            hipLaunchKernelGGL(paint_1x1_vec4_kernel, grid, dim3(256), 0, e->stream, pa);
+        else
+            hipLaunchKernelGGL(paint_tiles_kernel, grid, dim3(256), 0, e->stream, pa);
+        HIP_TRY(e, hipGetLastError());
+
+        if (!async) {
+            uint32_t mx[kMaxBatch];
+            HIP_TRY(e, hipMemcpyAsync(mx, e->words, 4 * nf, hipMemcpyDeviceToHost, e->stream));
+            HIP_TRY(e, hipStreamSynchronize(e->stream));
+            for (uint32_t f = 0; f < nf; ++f) {
+                if (max_out)
+                    max_out[f0 + f] = mx[f];
+                any_zero |= mx[f] == 0;
+            }
+        }
+    }
+    if (!async && any_zero && !raw_only)
+        return fail(e, STEPTH_ERR_MAX_ZERO, "a frame's distances are all 0; its output is all zero");
+    return STEPTH_OK;
+}
+
 int stepth_normalise_rows_pattern(stepth_engine *e, const stepth_image *rows, uint32_t first_row,
                                   uint32_t row_block, uint32_t row_mod, uint32_t row_rem,
                                   const uint32_t *max_ptr, uint32_t max_memory, uint32_t flags)
@@ -876,13 +1022,13 @@ int stepth_normalise_rows_pattern(stepth_engine *e, const stepth_image *rows, ui
     na.rows = rows->height;
     na.max_word = d_max;
     if (rows->memory == STEPTH_MEM_DEVICE) {
-        na.data = static_cast<uint8_t *>(const_cast<void *>(rows->data));
+        na.data[0] = static_cast<uint8_t *>(const_cast<void *>(rows->data));
         na.stride = rows->stride;
     } else {
         const uint8_t *dp = nullptr;
         size_t ds = 0;
         TRY(to_device(e, *rows, e->stage_out, dp, ds));
-        na.data = const_cast<uint8_t *>(dp);
+        na.data[0] = const_cast<uint8_t *>(dp);
         na.stride = ds;
     }
     const size_t total = (size_t)na.rows * na.w;
@@ -892,11 +1038,49 @@ int stepth_normalise_rows_pattern(stepth_engine *e, const stepth_image *rows, ui
     if (async)
         return STEPTH_OK;
     if (rows->memory == STEPTH_MEM_HOST)
-        HIP_TRY(e, hipMemcpy2DAsync(const_cast<void *>(rows->data), rows->stride, na.data,
+        HIP_TRY(e, hipMemcpy2DAsync(const_cast<void *>(rows->data), rows->stride, na.data[0],
                                     na.stride, na.w, na.rows, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     if (mx_host == 0)
         return fail(e, STEPTH_ERR_MAX_ZERO, "max is 0; rows zeroed");
+    return STEPTH_OK;
+}
+
+int stepth_normalise_rows_batch(stepth_engine *e, uint32_t n_frames, const stepth_image *rows,
+                                uint32_t first_row, uint32_t row_block, uint32_t row_mod,
+                                uint32_t row_rem, const uint32_t *max_ptr, uint32_t flags)
+{
+    if (!e)
+        return STEPTH_ERR_BAD_ARG;
+    if (n_frames == 0 || !rows || !max_ptr)
+        return fail(e, STEPTH_ERR_BAD_ARG, "empty batch or null pointer");
+    if (row_block && (row_mod == 0 || row_rem >= row_mod))
+        return fail(e, STEPTH_ERR_BAD_ARG, "row pattern: row_rem must be < row_mod");
+    for (uint32_t f = 0; f < n_frames; ++f) {
+        TRY(check_image(e, &rows[f], "rows", 1, 1));
+        if (rows[f].memory != STEPTH_MEM_DEVICE || rows[f].width != rows[0].width ||
+            rows[f].height != rows[0].height || rows[f].stride != rows[0].stride)
+            return fail(e, STEPTH_ERR_BAD_ARG, "batch: device images of one shape only");
+    }
+    HIP_TRY(e, hipSetDevice(e->device));
+    for (uint32_t f0 = 0; f0 < n_frames; f0 += kMaxBatch) {
+        const uint32_t nf = std::min<uint32_t>(kMaxBatch, n_frames - f0);
+        NormArgs na{};
+        for (uint32_t f = 0; f < nf; ++f)
+            na.data[f] = static_cast<uint8_t *>(const_cast<void *>(rows[f0 + f].data));
+        na.stride = rows[0].stride;
+        na.w = rows[0].width;
+        na.rows = rows[0].height;
+        na.max_word = max_ptr + f0;
+        na.first_row = first_row;
+        na.rp = RowPattern{row_block, row_block ? row_mod : 1u, row_block ? row_rem : 0u};
+        const size_t total = (size_t)na.rows * na.w;
+        const dim3 grid((uint32_t)std::min<size_t>((total + 255) / 256, 1024), nf);
+        hipLaunchKernelGGL(normalise_rows_kernel, grid, dim3(256), 0, e->stream, na);
+    }
+    HIP_TRY(e, hipGetLastError());
+    if (!(flags & STEPTH_FLAG_ASYNC))
+        HIP_TRY(e, hipStreamSynchronize(e->stream));
     return STEPTH_OK;
 }
 

@@ -855,70 +855,38 @@ struct FinishArgs {
 
 __global__ __launch_bounds__(256) void ring_finish_kernel(FinishArgs a)
 {
-    // Same-address atomics cost ~11 ns each chip-wide: the max is folded per workgroup and
-    // carried across its iterations, flushed only when the frame changes (records are ordered
-    // by frame, so that is about once per workgroup).
-    __shared__ uint32_t s_f[4], s_m[4], s_mixed;
-    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    // The frames of a batch interleave in the pending list, and same-address global atomics
+    // cost ~11 ns each chip-wide: the maxima are folded per frame in LDS and every workgroup
+    // flushes its non-zero entries once at the end.
+    __shared__ uint32_t s_fmax[kMaxBatch];
+    if (threadIdx.x < kMaxBatch)
+        s_fmax[threadIdx.x] = 0;
+    __syncthreads();
     const uint32_t count = *a.count;
-    uint32_t cur_f = ~0u, cur_m = 0; // thread 0: frame and max carried so far
-    for (uint32_t i0 = blockIdx.x * 256u; i0 < count; i0 += gridDim.x * 256u) {
-        const uint32_t i = i0 + threadIdx.x;
-        uint32_t d8 = 0, frame = ~0u;
-        if (i < count) {
-            const Query r = a.rec[i];
-            frame = r.cy >> 16;
-            const uint32_t key = a.key[i];
-            if (key != kNoKey) {
-                const uint32_t q = a.pending[i];
-                int dx, dy;
-                key_to_offset(key, a.pos_bits, dx, dy);
-                const uint32_t d = isqrt_floor((uint32_t)(dx * dx + dy * dy));
-                d8 = d & 0xffu;
-                a.raw[(size_t)frame * a.raw_stride + q] = (uint8_t)d8;
-                if (a.raw32)
-                    a.raw32[q] = d;
-                if (a.pos) {
-                    a.pos[2 * (size_t)q] = (uint32_t)((int)r.cx + dx);
-                    a.pos[2 * (size_t)q + 1] = (uint32_t)((int)(r.cy & 0xffffu) + dy);
-                }
-                if (a.found)
-                    a.found[q] = 1;
-            }
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < count; i += gridDim.x * 256u) {
+        const uint32_t key = a.key[i];
+        if (key == kNoKey)
+            continue;
+        const Query r = a.rec[i];
+        const uint32_t frame = r.cy >> 16, q = a.pending[i];
+        int dx, dy;
+        key_to_offset(key, a.pos_bits, dx, dy);
+        const uint32_t d = isqrt_floor((uint32_t)(dx * dx + dy * dy));
+        a.raw[(size_t)frame * a.raw_stride + q] = (uint8_t)(d & 0xffu);
+        if (d & 0xffu)
+            atomicMax(&s_fmax[frame], d & 0xffu);
+        if (a.raw32)
+            a.raw32[q] = d;
+        if (a.pos) {
+            a.pos[2 * (size_t)q] = (uint32_t)((int)r.cx + dx);
+            a.pos[2 * (size_t)q + 1] = (uint32_t)((int)(r.cy & 0xffffu) + dy);
         }
-        // lane 0 of a wave is its lowest record; records beyond `count` only follow valid ones
-        const uint32_t f0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)frame);
-        const bool wave_mixed = __builtin_amdgcn_ballot_w64(i < count && frame != f0) != 0;
-        const uint32_t m = wave_max_u32(d8);
-        if (threadIdx.x == 0)
-            s_mixed = 0;
-        __syncthreads();
-        if (lane == 0) {
-            s_f[wv] = f0;
-            s_m[wv] = m;
-            if (wave_mixed || (f0 != ~0u && f0 != (uint32_t)__builtin_amdgcn_readfirstlane(
-                                                       (int)a.rec[i0].cy) >> 16))
-                s_mixed = 1; // this workgroup's 256 records straddle a frame boundary
-        }
-        __syncthreads();
-        if (s_mixed) { // rare: every lane for itself
-            if (d8)
-                atomicMax(&a.max_word[frame], d8);
-        } else if (threadIdx.x == 0) {
-            const uint32_t f = s_f[0]; // wave 0 always holds valid records here
-            const uint32_t mm = max(max(s_m[0], s_m[1]), max(s_m[2], s_m[3]));
-            if (f != cur_f) {
-                if (cur_m)
-                    atomicMax(&a.max_word[cur_f], cur_m);
-                cur_f = f;
-                cur_m = 0;
-            }
-            cur_m = max(cur_m, mm);
-        }
-        __syncthreads();
+        if (a.found)
+            a.found[q] = 1;
     }
-    if (threadIdx.x == 0 && cur_m)
-        atomicMax(&a.max_word[cur_f], cur_m);
+    __syncthreads();
+    if (threadIdx.x < kMaxBatch && s_fmax[threadIdx.x])
+        atomicMax(&a.max_word[threadIdx.x], s_fmax[threadIdx.x]);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1022,7 +990,7 @@ __global__ __launch_bounds__(256) void paint_list_kernel(PaintArgs a)
 
 // in-place PASS 2 on already painted rows (row-strip sharding, after the cross-rank max)
 struct NormArgs {
-    uint8_t *data;
+    uint8_t *data[kMaxBatch]; // one image (view) per frame, blockIdx.y
     size_t stride;
     uint32_t w, rows;
     const uint32_t *max_word;
@@ -1033,13 +1001,14 @@ struct NormArgs {
 __global__ __launch_bounds__(256) void normalise_rows_kernel(NormArgs a)
 {
     __shared__ uint8_t lut[256];
-    build_lut(lut, a.max_word, 0);
+    build_lut(lut, a.max_word + blockIdx.y, 0);
+    uint8_t *data = a.data[blockIdx.y];
     const size_t total = (size_t)a.rows * a.w;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (size_t)gridDim.x * blockDim.x) {
         if (!a.rp.owns(a.first_row + (uint32_t)(i / a.w)))
             continue;
-        uint8_t *p = a.data + (size_t)(i / a.w) * a.stride + (i % a.w);
+        uint8_t *p = data + (size_t)(i / a.w) * a.stride + (i % a.w);
         *p = lut[*p];
     }
 }

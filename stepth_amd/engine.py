@@ -184,6 +184,52 @@ class Engine:
         self._check(st)
         return out, int(mx.value)
 
+    def depth_from_additional_batch(self, mains, additionals, precision, *, max_steps: int = 255,
+                                    rows: Optional[Tuple[int, int]] = None,
+                                    row_pattern: Optional[Tuple[int, int, int]] = None,
+                                    raw_only: bool = False, outs=None, max_out=None,
+                                    asynchronous: bool = False):
+        """stepth_depth_from_additional_batch: many frames (CUDA uint8 tensors of equal shape) in
+        one set of launches, ring mode, one group per pixel.  Returns (outs, max): `outs` a list
+        of [H,W] tensors; max a list of ints, or None with asynchronous=True (then `max_out`
+        must be a CUDA int32 tensor with one element per frame, or None)."""
+        import torch
+        n = len(mains)
+        if n == 0 or len(additionals) != n:
+            raise ValueError("mains and additionals must be equally long, non-empty lists")
+        if outs is None:
+            outs = [torch.zeros(m.shape[:2], dtype=torch.uint8, device=m.device) for m in mains]
+        mi = (L.Image * n)()
+        ai = (L.Image * n)()
+        di = (L.Image * n)()
+        keep = []
+        for f in range(n):
+            mi[f], k1 = _describe(mains[f], (3, 4), "main")
+            ai[f], k2 = _describe(additionals[f], (3,), "additional")
+            di[f], k3 = _describe(outs[f], (1,), "depth")
+            keep += [k1, k2, k3]
+        p = L.Params()
+        p.struct_size = C.sizeof(L.Params)
+        p.mode = L.MODE_RING_FIRST_HIT
+        p.precision = _u8x3(precision)
+        p.max_steps = max_steps
+        p.tile_w = p.tile_h = 1
+        if rows is not None:
+            p.row_begin, p.row_end = rows
+        if row_pattern is not None:
+            p.row_block, p.row_mod, p.row_rem = row_pattern
+        p.flags = (L.FLAG_ASYNC if asynchronous else 0) | (L.FLAG_RAW_ONLY if raw_only else 0)
+        if asynchronous:
+            mptr = max_out.data_ptr() if max_out is not None else None
+            self._check(self._lib.stepth_depth_from_additional_batch(self._h, n, mi, ai,
+                                                                     C.byref(p), di, mptr))
+            return outs, None
+        mx = (C.c_uint32 * n)()
+        st = self._lib.stepth_depth_from_additional_batch(self._h, n, mi, ai, C.byref(p), di,
+                                                          C.cast(mx, C.c_void_p))
+        self._check(st)
+        return outs, [int(v) for v in mx]
+
     def normalise_rows(self, rows, max_value, asynchronous: bool = False, first_row: int = 0,
                        row_pattern: Optional[Tuple[int, int, int]] = None):
         """stepth_normalise_rows[_pattern], in place.  max_value: int (host) or CUDA tensor
@@ -203,6 +249,22 @@ class Engine:
                                                          L.MEM_HOST, flags)
         self._check(st)
         return rows
+
+    def normalise_rows_batch(self, rows_list, max_tensor, asynchronous: bool = False,
+                             first_row: int = 0,
+                             row_pattern: Optional[Tuple[int, int, int]] = None):
+        """stepth_normalise_rows_batch: PASS 2 on equally shaped CUDA views in one launch;
+        `max_tensor` holds one int32 per view."""
+        n = len(rows_list)
+        ri = (L.Image * n)()
+        keep = []
+        for f in range(n):
+            ri[f], k = _describe(rows_list[f], (1,), "rows")
+            keep.append(k)
+        rb, rm, rr = row_pattern if row_pattern is not None else (0, 1, 0)
+        self._check(self._lib.stepth_normalise_rows_batch(
+            self._h, n, ri, first_row, rb, rm, rr, max_tensor.data_ptr(),
+            L.FLAG_ASYNC if asynchronous else 0))
 
     def gaussian_same_size(self, src, out=None, asynchronous: bool = False):
         """stepth_gaussian_same_size: the reference's `.resize(w, h, Gaussian)` tail."""

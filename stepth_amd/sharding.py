@@ -79,6 +79,30 @@ class EngineStripWorker(StripWorker):
             self.engine.normalise_rows(rows, max_word, asynchronous=True, first_row=first_row,
                                        row_pattern=pattern)
 
+    # -- all frames of a step in one set of launches (ring mode, 1x1 tiles) ------------------
+    def can_batch(self) -> bool:
+        return self.kw["mode"] == 0 and tuple(self.kw["tile"]) == (1, 1)
+
+    def match_batch(self, frames, rows, pattern=None):
+        """PASS 1 for every frame -> (list of raw views [r1-r0, W], max int32 [F])."""
+        mains = [f[0] for f in frames]
+        adds = [f[1] for f in frames]
+        h, w = mains[0].shape[0], mains[0].shape[1]
+        dev = mains[0].device
+        fulls = [torch.empty((h, w), dtype=torch.uint8, device=dev) for _ in frames]
+        mx = torch.zeros(len(frames), dtype=torch.int32, device=dev)
+        if rows[1] > rows[0]:
+            self.engine.depth_from_additional_batch(mains, adds, self.precision,
+                                                    max_steps=self.kw["max_steps"], rows=rows,
+                                                    row_pattern=pattern, raw_only=True,
+                                                    outs=fulls, max_out=mx, asynchronous=True)
+        return [f[rows[0]:rows[1]] for f in fulls], mx
+
+    def normalise_batch(self, rows_list, max_all, first_row=0, pattern=None):
+        if rows_list and rows_list[0].shape[0]:
+            self.engine.normalise_rows_batch(rows_list, max_all, asynchronous=True,
+                                             first_row=first_row, row_pattern=pattern)
+
 
 def sharded_depth(worker: StripWorker, frames: Sequence, height: int, width: int,
                   tile_h: int = 1, group: Optional[dist.ProcessGroup] = None,
@@ -113,9 +137,14 @@ def sharded_depth(worker: StripWorker, frames: Sequence, height: int, width: int
         r0, r1 = bounds[rank]
         rows_max = max(b - a for a, b in bounds)
 
+    batched = getattr(worker, "can_batch", lambda: False)() and n > 0 and \
+        hasattr(frames[0][0], "is_cuda") and frames[0][0].is_cuda
     strips, maxes = [], []
     max_buf = None
-    for i, f in enumerate(frames):
+    if batched:
+        strips, max_buf = worker.match_batch(frames, (r0, r1), pattern)
+        maxes = [max_buf]
+    for i, f in enumerate([] if batched else frames):
         kw = {"pattern": pattern} if pattern else {}
         if i == 0:
             raw, mx = worker.match_strip(f, (r0, r1), **kw)
@@ -129,7 +158,9 @@ def sharded_depth(worker: StripWorker, frames: Sequence, height: int, width: int
         maxes.append(mx)
     if device is None:
         device = maxes[0].device
-    if max_buf is not None:
+    if batched:
+        max_all = max_buf
+    elif max_buf is not None:
         max_buf[0:1] = maxes[0].reshape(1)
         max_all = max_buf
     else:
@@ -145,7 +176,9 @@ def sharded_depth(worker: StripWorker, frames: Sequence, height: int, width: int
             max_all = m_host.to(device)
         else:
             dist.all_reduce(max_all, op=dist.ReduceOp.MAX, group=group)  # src/depth_image.rs:124
-    for i, raw in enumerate(strips):  # src/depth_image.rs:125-129
+    if batched:  # src/depth_image.rs:125-129
+        worker.normalise_batch(strips, max_all, first_row=r0, pattern=pattern)
+    for i, raw in enumerate([] if batched else strips):
         if pattern:
             worker.normalise(raw, max_all[i:i + 1], first_row=r0, pattern=pattern)
         else:

@@ -356,6 +356,61 @@ def test_interleaved_row_blocks_compose_to_the_full_frame(engine, oracle, tile, 
         engine.depth_from_additional(l, r, P36, row_pattern=(4, 2, 2))   # rem >= mod
 
 
+def test_batch_of_frames_equals_frame_by_frame(engine, oracle):
+    """stepth_depth_from_additional_batch: many frames in one set of launches, each frame
+    normalised by its own max; also > 32 frames (chunked), strips, row patterns, async"""
+    import torch
+    from stepth_amd import synth, MaxZeroError
+    frames = []
+    for i in range(5):
+        l, r, _ = synth.stereo_pair(150, 90, 32, seed=40 + i)
+        if i == 3:
+            r = np.ascontiguousarray(r[::-1])  # a frame with a different max
+        frames.append((l, r))
+    refs = [oracle.depth_from_additional(l, r, P36, 64) for l, r in frames]
+    assert len({ref["max"] for ref in refs}) > 1
+    dm = [torch.from_numpy(l).cuda() for l, _ in frames]
+    da = [torch.from_numpy(r).cuda() for _, r in frames]
+    outs, mx = engine.depth_from_additional_batch(dm, da, P36, max_steps=64)
+    for o, m, ref in zip(outs, mx, refs):
+        np.testing.assert_array_equal(o.cpu().numpy(), ref["depth"])
+        assert m == ref["max"]
+    # 40 frames -> two chunks; raw_only; async with device maxima
+    many_m, many_a = [dm[i % 5] for i in range(40)], [da[i % 5] for i in range(40)]
+    mxd = torch.zeros(40, dtype=torch.int32, device="cuda")
+    engine.use_torch_stream()
+    try:
+        outs, none = engine.depth_from_additional_batch(many_m, many_a, P36, max_steps=64,
+                                                        raw_only=True, max_out=mxd,
+                                                        asynchronous=True)
+        assert none is None
+        for i, o in enumerate(outs):
+            np.testing.assert_array_equal(o.cpu().numpy(), refs[i % 5]["raw"])
+        assert mxd.tolist() == [refs[i % 5]["max"] for i in range(40)]
+    finally:
+        engine.reset_stream()
+    # strips and interleaved patterns compose, per frame
+    outs = [torch.full((90, 150), 7, dtype=torch.uint8, device="cuda") for _ in range(5)]
+    maxes = np.zeros((3, 5), int)
+    for rank in range(3):
+        _, mx = engine.depth_from_additional_batch(dm, da, P36, max_steps=64, raw_only=True,
+                                                   outs=outs, row_pattern=(4, 3, rank))
+        maxes[rank] = mx
+    for i, o in enumerate(outs):
+        np.testing.assert_array_equal(o.cpu().numpy(), refs[i]["raw"])
+    assert maxes.max(axis=0).tolist() == [ref["max"] for ref in refs]
+    outs = [torch.zeros((90, 150), dtype=torch.uint8, device="cuda") for _ in range(5)]
+    for rows in ((0, 31), (31, 90)):
+        engine.depth_from_additional_batch(dm, da, P36, max_steps=64, raw_only=True, outs=outs,
+                                           rows=rows)
+    for i, o in enumerate(outs):
+        np.testing.assert_array_equal(o.cpu().numpy(), refs[i]["raw"])
+    # a flat frame in the batch: defined outcome
+    flat = torch.full((90, 150, 3), 50, dtype=torch.uint8, device="cuda")
+    with pytest.raises(MaxZeroError):
+        engine.depth_from_additional_batch([dm[0], flat], [da[0], flat], P36, max_steps=64)
+
+
 def test_device_memory_async_path(engine, oracle):
     import torch
     from stepth_amd import synth
