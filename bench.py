@@ -5,7 +5,7 @@ Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 la
 torch.distributed.run, one rank per GPU.  Rank 0 prints ONE JSON line.
 
 Workload (BASELINE.json metric: "Mpixels/sec depth output, 1080p stereo d_max=128"):
-  a step = one pass of the hot path over a batch of `frames_per_gpu * N` synthetic 1920x1080
+  a step = one pass of the hot path over a batch of `8 * N` synthetic 1920x1080
   stereo pairs (inputs resident in HBM), reference-exact mode (square-ring first hit,
   /root/reference/src/helpers.rs:9-54), one group per pixel, max_steps = d_max = 128,
   precision [36;3] (Readme.md:14).  All frames of a step go through ONE set of launches
@@ -109,7 +109,8 @@ def main():
     ap.add_argument("--d-max", dest="d_max", type=int, default=128)
     ap.add_argument("--win", type=int, default=5)
     ap.add_argument("--precision", type=int, default=36)
-    ap.add_argument("--frames-per-gpu", dest="fpg", type=int, default=4)
+    ap.add_argument("--frames-per-gpu", dest="fpg", type=int, default=8,
+                    help="frames per step and GPU (BASELINE config 4: 64 pairs over 8 GPUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--interleave", type=int, default=16,
                     help="N > 1, ring mode: deal rows in interleaved blocks of this many rows "
@@ -217,9 +218,10 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "r1_ring_hbm_traffic.json")
         if args.mode == "ring" and world == 1 and (W, H, args.d_max) == (1920, 1080, 128) \
                 and os.path.exists(tpath):
-            per_frame = json.load(open(tpath)).get(
-                "ring_search_kernel_traffic_bytes_per_launch_corrected")
-            traffic = per_frame * frames_per_launch if per_frame else None  # profiled per frame
+            prof = json.load(open(tpath))
+            per_launch = prof.get("ring_search_kernel_traffic_bytes_per_launch_corrected")
+            if per_launch and prof.get("frames_per_launch"):  # scale to this run's batch size
+                traffic = int(per_launch * frames_per_launch / prof["frames_per_launch"])
         out = {
             "metric": ("Mpixels/sec depth output, 1080p stereo d_max=128" if args.mode == "ring"
                        else "Mpixels/sec depth output, windowed-SAD mode (not in the reference)"),

@@ -890,8 +890,13 @@ int stepth_depth_from_additional_batch(stepth_engine *e, uint32_t n_frames,
     const uint32_t rows = row1 - row0;
     bool any_zero = false;
 
-    for (uint32_t f0 = 0; f0 < n_frames; f0 += kMaxBatch) {
-        const uint32_t nf = std::min<uint32_t>(kMaxBatch, n_frames - f0);
+    // frames per set of launches: at most kMaxBatch, and few enough that all their cells can be
+    // indexed with 32 bits
+    const uint64_t cells = (uint64_t)((adds[0].width + 7u) / 8u) * ((adds[0].height + 7u) / 8u) * 64u;
+    const uint32_t chunk = (uint32_t)std::max<uint64_t>(
+        1, std::min<uint64_t>(kMaxBatch, 0x3FFFFFFFull / std::max<uint64_t>(cells, 1)));
+    for (uint32_t f0 = 0; f0 < n_frames; f0 += chunk) {
+        const uint32_t nf = std::min<uint32_t>(chunk, n_frames - f0);
         const uint8_t *d_adds[kMaxBatch];
         for (uint32_t f = 0; f < nf; ++f)
             d_adds[f] = static_cast<const uint8_t *>(adds[f0 + f].data);
