@@ -115,6 +115,14 @@ def load():
             f"{LIB_PATH} not found: the stepth_amd HIP extension is not built. Run "
             "`python -c 'import __graft_entry__ as g; g.build()'` (or make -C stepth_amd/csrc). "
             "There is no CPU fallback.")
+    # PyTorch-ROCm wheels bundle their own libamdhip64/libhsa-runtime64.  Two HSA runtimes in
+    # one process cannot both own the GPU ("No HIP GPUs are available" for whichever comes
+    # second), so when torch is installed it is imported first: the engine library then binds
+    # to the runtime torch has already loaded (same SONAME) and both share it.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the .so is stale
