@@ -259,6 +259,8 @@ int launch_ring(stepth_engine *e, RingArgs &ra, int qmode, uint32_t n_frames = 1
     if (ra.n == 0)
         return STEPTH_OK;
     const uint32_t slots = qmode == 0 ? ra.n_slots : ra.n;
+    if (slots == 0) // a row pattern can leave a rank without rows
+        return STEPTH_OK;
     const uint32_t blocks = (slots + 256u * kRing0Iters - 1u) / (256u * kRing0Iters);
     TRY(ensure_spiral(e, ra.max_steps, ra.wa, ra.ha));
     {

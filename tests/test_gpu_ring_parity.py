@@ -580,3 +580,53 @@ def test_images_beyond_the_cell_index_range_are_refused(engine):
                                                   C.byref(p), None, 0, 0, C.byref(depth), None)
     assert st == L.ERR_BAD_ARG
     assert b"2^30" in engine._lib.stepth_last_error(engine._h)
+
+
+def test_randomised_small_cases(engine, oracle):
+    """300 random small configurations (sizes, unequal image sizes, precision per channel incl.
+    0 and 255, max_steps incl. 0/1 and > 255, tiles, strips, patterns, noise vs smooth) --
+    bit-exact against the oracle"""
+    from stepth_amd import MaxZeroError, synth
+    rng = np.random.default_rng(2024)
+    smooth = synth.stereo_pair(96, 80, 16, seed=77)
+    for case in range(300):
+        w, h = int(rng.integers(1, 48)), int(rng.integers(1, 40))
+        wa, ha = (w, h) if rng.random() < 0.6 else (int(rng.integers(1, 60)), int(rng.integers(1, 50)))
+        if rng.random() < 0.5:
+            main = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+            add = rng.integers(0, 256, (ha, wa, 3), dtype=np.uint8)
+            if rng.random() < 0.5:  # coarse colours -> plenty of far matches
+                main, add = main // 64 * 64, add // 64 * 64
+        else:
+            main = np.ascontiguousarray(smooth[0][:h, :w])
+            add = np.ascontiguousarray(smooth[1][:ha, :wa])
+        prec = [int(v) for v in rng.choice([0, 1, 2, 9, 36, 80, 255], 3)] if rng.random() < 0.3 \
+            else [int(rng.integers(1, 90))] * 3
+        ms = int(rng.choice([0, 1, 2, 3, 8, 9, 24, 25, 26, 64, 255, 300]))
+        tile = (1, 1) if rng.random() < 0.6 else (int(rng.integers(1, 7)), int(rng.integers(1, 7)))
+        ref = oracle.depth_from_additional(main, add, prec, ms, tile)
+        kw = dict(max_steps=ms, tile=tile)
+        mode = rng.integers(0, 3)
+        if mode == 0:  # whole frame
+            try:
+                d, mx = engine.depth_from_additional(main, add, prec, **kw)
+                assert ref["status"] == 0 and mx == ref["max"], (case, w, h, prec, ms, tile)
+                np.testing.assert_array_equal(d, ref["depth"], err_msg=str((case, w, h, prec, ms, tile)))
+            except MaxZeroError:
+                assert ref["status"] == oracle.ERR_MAX_ZERO, (case, w, h, prec, ms, tile)
+        else:
+            out = np.zeros((h, w), np.uint8)
+            maxes = []
+            if mode == 1:  # contiguous strips, tile aligned
+                cuts = sorted(set([0, h] + [int(c) // tile[1] * tile[1] for c in rng.integers(0, h + 1, 2)]))
+                parts = [dict(rows=(a, b)) for a, b in zip(cuts, cuts[1:])]
+            else:          # interleaved blocks
+                blk = 2 * tile[1] * int(rng.integers(1, 4))
+                mod = int(rng.integers(1, 4))
+                parts = [dict(row_pattern=(blk, mod, r)) for r in range(mod)]
+            for part in parts:
+                _, mx = engine.depth_from_additional(main, add, prec, raw_only=True, out=out,
+                                                     **kw, **part)
+                maxes.append(mx)
+            np.testing.assert_array_equal(out, ref["raw"], err_msg=str((case, w, h, prec, ms, tile, parts)))
+            assert max(maxes) == ref["max"]
