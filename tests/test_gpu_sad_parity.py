@@ -51,3 +51,30 @@ def test_sad_larger_frame_band_and_planted_disparity(engine, oracle):
     inner = (slice(8, -8), slice(72, -8))
     # piecewise-flat texture is ambiguous for a 5x5 window; measured 0.48
     assert (np.abs(raw[inner].astype(int) - disp[inner]) <= 1).mean() > 0.35
+
+
+def test_sad_randomised_small_cases(engine, oracle):
+    """80 random configurations: sizes (also narrower than a wave / the window), d_max not a
+    multiple of the disparity chunk, every odd window 1..11, thresholds, strips"""
+    rng = np.random.default_rng(7)
+    for case in range(80):
+        w, h = int(rng.integers(1, 150)), int(rng.integers(1, 40))
+        d_max = int(rng.choice([1, 2, 7, 16, 17, 33, 64, 100, 128, 256]))
+        win = int(rng.choice([1, 3, 5, 7, 9, 11]))
+        l = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        shift = int(rng.integers(0, min(d_max, w)))
+        r = np.roll(l, -shift, axis=1)
+        r = np.clip(r.astype(int) + rng.integers(-3, 4, r.shape), 0, 255).astype(np.uint8)
+        prec = [int(rng.choice([0, 2, 10, 60]))] * 3
+        ref = oracle.sad_rows(l, r, d_max, win, prec)
+        if rng.random() < 0.5:
+            raw, mx = run_sad(engine, l, r, d_max, win, prec, raw_only=True)
+        else:
+            raw = np.zeros((h, w), np.uint8)
+            cut = int(rng.integers(0, h + 1))
+            mx = 0
+            for rows in ((0, cut), (cut, h)):
+                _, m = run_sad(engine, l, r, d_max, win, prec, raw_only=True, rows=rows, out=raw)
+                mx = max(mx, m)
+        np.testing.assert_array_equal(raw, ref, err_msg=str((case, w, h, d_max, win, prec)))
+        assert mx == int(ref.max())
