@@ -104,6 +104,18 @@ class EngineStripWorker(StripWorker):
                                              first_row=first_row, row_pattern=pattern)
 
 
+_OWNED_CACHE: dict = {}
+
+
+def _owned_rows(height: int, block: int, world: int) -> List[torch.Tensor]:
+    """row indices owned by each rank under the interleaved pattern (cached)"""
+    key = (height, block, world)
+    if key not in _OWNED_CACHE:
+        ys = torch.arange(height)
+        _OWNED_CACHE[key] = [ys[(ys // block) % world == r] for r in range(world)]
+    return _OWNED_CACHE[key]
+
+
 def sharded_depth(worker: StripWorker, frames: Sequence, height: int, width: int,
                   tile_h: int = 1, group: Optional[dist.ProcessGroup] = None,
                   device: Optional[torch.device] = None,
@@ -127,8 +139,7 @@ def sharded_depth(worker: StripWorker, frames: Sequence, height: int, width: int
     pattern = None
     if interleave and world > 1:
         pattern = (interleave, world, rank)
-        owned = [torch.tensor([y for y in range(height) if (y // interleave) % world == r],
-                              dtype=torch.long) for r in range(world)]
+        owned = _owned_rows(height, interleave, world)
         bounds = [(0, height)] * world
         r0, r1 = 0, height
         rows_max = max(len(o) for o in owned)
