@@ -89,13 +89,15 @@ class EngineStripWorker(StripWorker):
         adds = [f[1] for f in frames]
         h, w = mains[0].shape[0], mains[0].shape[1]
         dev = mains[0].device
-        fulls = [torch.empty((h, w), dtype=torch.uint8, device=dev) for _ in frames]
+        base = torch.empty((len(frames), h, w), dtype=torch.uint8, device=dev)
+        fulls = [base[i] for i in range(len(frames))]  # all frames in one allocation
         mx = torch.zeros(len(frames), dtype=torch.int32, device=dev)
         if rows[1] > rows[0]:
             self.engine.depth_from_additional_batch(mains, adds, self.precision,
                                                     max_steps=self.kw["max_steps"], rows=rows,
                                                     row_pattern=pattern, raw_only=True,
                                                     outs=fulls, max_out=mx, asynchronous=True)
+        self.last_base = base  # [F, H, W]; lets the caller gather rows of all frames at once
         return [f[rows[0]:rows[1]] for f in fulls], mx
 
     def normalise_batch(self, rows_list, max_all, first_row=0, pattern=None):
@@ -114,6 +116,16 @@ def _owned_rows(height: int, block: int, world: int) -> List[torch.Tensor]:
         ys = torch.arange(height)
         _OWNED_CACHE[key] = [ys[(ys // block) % world == r] for r in range(world)]
     return _OWNED_CACHE[key]
+
+
+_OWNED_DEV: dict = {}
+
+
+def _owned_on(owned: List[torch.Tensor], r: int, device) -> torch.Tensor:
+    key = (id(owned), r, str(device))
+    if key not in _OWNED_DEV:
+        _OWNED_DEV[key] = owned[r].to(device)
+    return _OWNED_DEV[key]
 
 
 def sharded_depth(worker: StripWorker, frames: Sequence, height: int, width: int,
@@ -196,16 +208,25 @@ def sharded_depth(worker: StripWorker, frames: Sequence, height: int, width: int
             worker.normalise(raw, max_all[i:i + 1])
 
     if world == 1:
+        if batched and getattr(worker, "last_base", None) is not None:
+            return worker.last_base[:, r0:r1], max_all
         return torch.stack([s for s in strips]), max_all
 
     send = torch.zeros((n, rows_max, width), dtype=torch.uint8, device=device)
+    base = getattr(worker, "last_base", None) if batched else None
     if pattern:
-        mine = owned[rank].to(device)
-        for i, raw in enumerate(strips):
-            send[i, : len(mine)] = raw.index_select(0, mine)
+        mine = _owned_on(owned, rank, device)
+        if base is not None:
+            send[:, : len(mine)] = base.index_select(1, mine)
+        else:
+            for i, raw in enumerate(strips):
+                send[i, : len(mine)] = raw.index_select(0, mine)
     elif r1 > r0:
-        for i, raw in enumerate(strips):
-            send[i, : r1 - r0] = raw
+        if base is not None:
+            send[:, : r1 - r0] = base[:, r0:r1]
+        else:
+            for i, raw in enumerate(strips):
+                send[i, : r1 - r0] = raw
     if sync:
         sync()
     if dst is not None:
@@ -228,7 +249,7 @@ def sharded_depth(worker: StripWorker, frames: Sequence, height: int, width: int
     if pattern:
         for r in range(world):
             if len(owned[r]):
-                depth[:, owned[r].to(device)] = recv[r, :, : len(owned[r])]
+                depth[:, _owned_on(owned, r, device)] = recv[r, :, : len(owned[r])]
         return depth, max_all
     for r, (a, b) in enumerate(bounds):
         if b > a:
