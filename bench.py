@@ -112,9 +112,10 @@ def main():
     ap.add_argument("--frames-per-gpu", dest="fpg", type=int, default=8,
                     help="frames per step and GPU (BASELINE config 4: 64 pairs over 8 GPUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--interleave", type=int, default=16,
+    ap.add_argument("--interleave", type=int, default=0,
                     help="N > 1, ring mode: deal rows in interleaved blocks of this many rows "
-                         "(0 = contiguous strips); balances the data-dependent work")
+                         "(0 = contiguous strips, a few % faster on the bench frames; blocks of 16 "
+                         "balance the data-dependent work whatever the image content)")
     ap.add_argument("--backend", default="nccl",
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
                          "the multi-rank path with several ranks on one GPU)")
