@@ -660,24 +660,25 @@ __global__ __launch_bounds__(256) STEPTH_SEARCH_ATTR void ring_search_kernel(Sea
             // every member the block can still help; keys only on a hit
             auto resolve = [&](int sbi, int sbj, uint32_t type, uint32_t d, uint32_t cell,
                                uint32_t c) -> bool {
-                bool hit[4], any = false;
+                // hit masks per member (wave-uniform 64-bit values)
+                unsigned long long h[4];
 #pragma unroll
-                for (uint32_t m = 0; m < 4; ++m) {
-                    hit[m] = d < limit[m] && cell_in_box(c, qlo[m], qhi[m]);
-                    any |= hit[m];
-                }
-                if (!ballot(any))
+                for (uint32_t m = 0; m < 4; ++m)
+                    h[m] = d < limit[m] ? ballot(cell_in_box(c, qlo[m], qhi[m])) : 0ull;
+                if (!(h[0] | h[1] | h[2] | h[3]))
                     return false;
                 uint32_t ring;
                 const uint32_t key = scan_key(sbi * 8 + (int)(cell & 7u) + nox,
                                               sbj * 8 + (int)(cell >> 3) + noy, a.pos_bits, ring);
+                const unsigned long long in_reach = ballot(ring < s_end);
                 bool changed = false;
 #pragma unroll
                 for (uint32_t m = 0; m < 4; ++m) {
-                    const unsigned long long hm = ballot(hit[m] && ring < s_end);
+                    const unsigned long long hm = h[m] & in_reach;
                     if (hm) {
-                        const uint32_t k = type < 4u ? bcast(key, __ffsll(hm) - 1)
-                                                     : wave_min_dpp(hit[m] && ring < s_end ? key : kNoKey);
+                        const uint32_t k = type < 4u
+                                               ? bcast(key, __ffsll(hm) - 1)
+                                               : wave_min_dpp(((hm >> lane) & 1ull) ? key : kNoKey);
                         best[m] = min(best[m], k);
                         limit[m] = min(limit[m], (best[m] >> ring_shift) + 1u);
                         changed = true;
