@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define STEPTH_ABI_VERSION 1u
+#define STEPTH_ABI_VERSION 2u
 
 typedef struct stepth_engine stepth_engine; /* opaque */
 
@@ -44,7 +44,15 @@ typedef enum {
      * (src/depth_image.rs:127); here the output is all zero and this status is returned */
     STEPTH_ERR_MAX_ZERO = -4,
     STEPTH_ERR_NO_DEVICE = -5,
-    STEPTH_ERR_OUT_OF_MEMORY = -6
+    STEPTH_ERR_OUT_OF_MEMORY = -6,
+    /* depth_split inputs on which the reference panics (src/depth_image.rs:162-219):
+     * (max - min) / (zones - 1) < 2 makes `step_by` assert or its argument underflow (:217) */
+    STEPTH_ERR_SPLIT_STEP = -7,
+    /* a zone with no pixels at convergence: `.min().unwrap()` of nothing (:203-206) */
+    STEPTH_ERR_SPLIT_EMPTY_ZONE = -8,
+    /* the centroid iteration did not settle within 4096 passes (the reference recurses
+     * without a bound, :210) */
+    STEPTH_ERR_SPLIT_DIVERGED = -9
 } stepth_status;
 
 typedef enum {
@@ -210,6 +218,60 @@ int stepth_distance_dot_array_batch(stepth_engine *engine, const stepth_image *a
                                     const uint8_t *what, const uint32_t *from_xy, size_t n,
                                     uint32_t max, const uint8_t precision[3], uint8_t *found,
                                     uint32_t *dist, uint32_t *pos_xy);
+
+/* ---- consumers of a finished depth map (README's second half, Readme.md:18-24) --------- */
+
+/* one `(Option<u8>, Option<u8>)` of depth_split's result / slice's arguments */
+typedef struct stepth_zone {
+    uint8_t has_from, from; /* has_from = 0 is None -> 0   (src/depth_image.rs:231) */
+    uint8_t has_to, to;     /* has_to   = 0 is None -> 255 (src/depth_image.rs:232) */
+} stepth_zone;
+
+/*
+ * DepthImage::invert_depth, src/depth_image.rs:226-228: every byte of `depth` becomes
+ * 255 - byte, in place ([H][W] u8, host or device).
+ */
+int stepth_invert_depth(stepth_engine *engine, const stepth_image *depth, uint32_t flags);
+
+/*
+ * DepthImage::depth_split(zones), src/depth_image.rs:162-219: 1-D k-means over the depth
+ * bytes; writes the zones as (Some(min), Some(max)) in centroid order to out[0..*n_out).
+ * zones < 2 gives the single zone (None, None) (:163-165).  `capacity` entries are available
+ * at `out` (255 always suffice); more zones than that is STEPTH_ERR_BAD_ARG.  Inputs on which
+ * the reference panics return STEPTH_ERR_SPLIT_*.  Synchronous.
+ */
+int stepth_depth_split(stepth_engine *engine, const stepth_image *depth, uint32_t zones,
+                       stepth_zone *out, uint32_t capacity, uint32_t *n_out);
+
+/*
+ * DepthImage::slice(from, to), src/depth_image.rs:230-247, the mask plane of the returned
+ * MaskImage: mask = 255 (MASK_TRUE, src/mask_image.rs:3) unless depth < from or depth > to,
+ * then 0 (MASK_FALSE, :4).  `mask` [H][W] u8 of the depth map's size, else
+ * STEPTH_ERR_SIZE_MISMATCH.
+ */
+int stepth_slice(stepth_engine *engine, const stepth_image *depth, const stepth_zone *range,
+                 const stepth_image *mask, uint32_t flags);
+
+/*
+ * DepthImage::select_foreground, src/depth_image.rs:221-224: slice(depth_split(2)[0]).
+ * zone_out (optional) receives that zone.  The batch form runs n frames of one shape in
+ * three launches (histogram, split, slice) and needs device memory; statuses[f] (optional)
+ * is STEPTH_OK or the STEPTH_ERR_SPLIT_* of frame f, whose mask is then left unwritten, and
+ * the call returns the first non-OK frame status.  With STEPTH_FLAG_ASYNC the batch form only
+ * enqueues: zones_out/statuses must be NULL and failed frames simply keep their mask.
+ */
+int stepth_select_foreground(stepth_engine *engine, const stepth_image *depth,
+                             const stepth_image *mask, stepth_zone *zone_out);
+int stepth_select_foreground_batch(stepth_engine *engine, uint32_t n_frames,
+                                   const stepth_image *depths, const stepth_image *masks,
+                                   stepth_zone *zones_out, int *statuses, uint32_t flags);
+
+/*
+ * MaskImage::apply_mask, src/mask_image.rs:205-213: RGBA pixels whose mask byte is 0 become
+ * [0;4], in place.  rgba [H][W][4], mask [H][W] u8 of the same size.
+ */
+int stepth_apply_mask(stepth_engine *engine, const stepth_image *rgba, const stepth_image *mask,
+                      uint32_t flags);
 
 /* Counting costs a little kernel time, so it is off by default: enable it, run a call, read
  * the counters of that call (synchronises the stream). */

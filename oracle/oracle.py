@@ -86,6 +86,18 @@ def lib(path: Optional[str] = None):
     L.oracle_gaussian_same_size.restype = None
     L.oracle_gaussian_same_size.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_size_t,
                                             C.c_void_p, C.c_size_t]
+    L.oracle_depth_split.restype = C.c_int
+    L.oracle_depth_split.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, u8p, u8p, u8p,
+                                     C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.oracle_invert_depth.restype = None
+    L.oracle_invert_depth.argtypes = [C.c_void_p, C.c_size_t]
+    L.oracle_slice.restype = None
+    L.oracle_slice.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_uint8, C.c_int, C.c_uint8,
+                               C.c_void_p]
+    L.oracle_select_foreground.restype = C.c_int
+    L.oracle_select_foreground.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, u8p, u8p]
+    L.oracle_apply_mask.restype = None
+    L.oracle_apply_mask.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     L.oracle_hardware_threads.restype = C.c_int
     L.oracle_set_threads.restype = None
     L.oracle_set_threads.argtypes = [C.c_int]
@@ -218,6 +230,55 @@ def gaussian_same_size(img: np.ndarray) -> np.ndarray:
     out = np.zeros_like(img)
     h, w = img.shape
     lib().oracle_gaussian_same_size(img.ctypes.data, w, h, img.strides[0], out.ctypes.data, w)
+    return out
+
+
+SPLIT_ERR_STEP, SPLIT_ERR_EMPTY, SPLIT_ERR_DIVERGED, SPLIT_ERR_INPUT = -7, -8, -9, -1
+
+
+def depth_split(depth: np.ndarray, zones: int):
+    """src/depth_image.rs:162-219 -> {"status", "zones": [(lo|None, hi|None), ...], "iters"}"""
+    depth = np.ascontiguousarray(depth, dtype=np.uint8)
+    lo, hi, has = ((C.c_uint8 * 256)() for _ in range(3))
+    n, it = C.c_uint32(0), C.c_uint32(0)
+    rc = lib().oracle_depth_split(depth.ctypes.data, depth.size, zones, lo, hi, has,
+                                  C.byref(n), C.byref(it))
+    zs = [((lo[i], hi[i]) if has[i] else (None, None)) for i in range(n.value)] if rc == 0 else []
+    return {"status": rc, "zones": zs, "iters": it.value}
+
+
+def invert_depth(depth: np.ndarray) -> np.ndarray:
+    """src/depth_image.rs:226-228 (returns a new array)"""
+    out = np.array(depth, dtype=np.uint8, order="C")
+    lib().oracle_invert_depth(out.ctypes.data, out.size)
+    return out
+
+
+def slice_mask(depth: np.ndarray, from_: Optional[int], to: Optional[int]) -> np.ndarray:
+    """src/depth_image.rs:230-247, the mask plane only"""
+    depth = np.ascontiguousarray(depth, dtype=np.uint8)
+    mask = np.empty_like(depth)
+    lib().oracle_slice(depth.ctypes.data, depth.size, from_ is not None, from_ or 0,
+                       to is not None, 255 if to is None else to, mask.ctypes.data)
+    return mask
+
+
+def select_foreground(depth: np.ndarray):
+    """src/depth_image.rs:221-224 -> {"status", "mask", "zone"}"""
+    depth = np.ascontiguousarray(depth, dtype=np.uint8)
+    mask = np.zeros_like(depth)
+    f, t = C.c_uint8(0), C.c_uint8(0)
+    rc = lib().oracle_select_foreground(depth.ctypes.data, depth.size, mask.ctypes.data,
+                                        C.byref(f), C.byref(t))
+    return {"status": rc, "mask": mask, "zone": (f.value, t.value) if rc == 0 else None}
+
+
+def apply_mask(rgba: np.ndarray, mask: np.ndarray) -> np.ndarray:
+    """src/mask_image.rs:205-213 (returns a new array)"""
+    out = np.array(rgba, dtype=np.uint8, order="C")
+    assert out.ndim == 3 and out.shape[2] == 4 and mask.shape == out.shape[:2]
+    mask = np.ascontiguousarray(mask, dtype=np.uint8)
+    lib().oracle_apply_mask(out.ctypes.data, mask.ctypes.data, mask.size)
     return out
 
 

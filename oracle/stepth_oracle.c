@@ -513,3 +513,145 @@ int oracle_sad_rows(const uint8_t *left, const uint8_t *right, uint32_t w, uint3
     free(tids);
     return ORACLE_OK;
 }
+
+/* ---- consumers of a finished depth map ------------------------------- */
+
+/* src/depth_image.rs:166-211, one call of `inner` per loop trip */
+int oracle_depth_split(const uint8_t *depth, size_t n, uint32_t zones, uint8_t *lo, uint8_t *hi,
+                       uint8_t *has, uint32_t *n_zones, uint32_t *iters)
+{
+    if (iters)
+        *iters = 0;
+    if (zones < 2) { /* :163-165 */
+        lo[0] = hi[0] = has[0] = 0;
+        *n_zones = 1;
+        return ORACLE_SPLIT_OK;
+    }
+    if (zones > 255 || n == 0) /* zones is a u8; :214 unwraps min() of nothing */
+        return ORACLE_SPLIT_ERR_INPUT;
+    uint8_t img_min = 255, img_max = 0; /* :214-215 */
+    for (size_t i = 0; i < n; ++i) {
+        if (depth[i] < img_min)
+            img_min = depth[i];
+        if (depth[i] > img_max)
+            img_max = depth[i];
+    }
+    /* :217  ((img_max - img_min) / (zones - 1)) as usize - 1 ; step_by(0) asserts */
+    const uint32_t q = (uint32_t)(uint8_t)(img_max - img_min) / (zones - 1);
+    if (q < 2)
+        return ORACLE_SPLIT_ERR_STEP;
+    const uint32_t step = q - 1;
+    uint8_t prev[256], next[256];
+    uint32_t n_prev = 0, n_next;
+    for (uint32_t c = img_min; c < img_max; c += step) /* :216-218, img_max exclusive */
+        prev[n_prev++] = (uint8_t)c;
+
+    uint64_t *sum = calloc(256, sizeof *sum), *cnt = calloc(256, sizeof *cnt);
+    uint8_t key[256], cmin[256], cmax[256];
+    int rc = ORACLE_SPLIT_ERR_DIVERGED;
+    for (uint32_t it = 1; it <= ORACLE_SPLIT_MAX_ITERS; ++it) {
+        if (iters)
+            *iters = it;
+        memset(sum, 0, 256 * sizeof *sum);
+        memset(cnt, 0, 256 * sizeof *cnt);
+        memset(key, 0, sizeof key);
+        memset(cmin, 255, sizeof cmin);
+        memset(cmax, 0, sizeof cmax);
+        for (uint32_t i = 0; i < n_prev; ++i) /* :167-170, duplicates share one entry */
+            key[prev[i]] = 1;
+        for (size_t i = 0; i < n; ++i) { /* :171-183 */
+            const int item = depth[i];
+            uint32_t best = 0;
+            int best_d = abs((int)prev[0] - item);
+            for (uint32_t k = 1; k < n_prev; ++k) { /* min_by keeps the first minimum */
+                const int d = abs((int)prev[k] - item);
+                if (d < best_d) {
+                    best_d = d;
+                    best = k;
+                }
+            }
+            const uint8_t c = prev[best];
+            sum[c] += (uint64_t)item;
+            cnt[c] += 1;
+            if (depth[i] < cmin[c])
+                cmin[c] = depth[i];
+            if (depth[i] > cmax[c])
+                cmax[c] = depth[i];
+        }
+        n_next = 0; /* :184-188: means in any order, then sort -- walk the keys and insert */
+        for (uint32_t c = 0; c < 256; ++c) {
+            if (!key[c])
+                continue;
+            const uint8_t m = (uint8_t)(sum[c] / (cnt[c] ? cnt[c] : 1));
+            uint32_t at = n_next++;
+            while (at > 0 && next[at - 1] > m) {
+                next[at] = next[at - 1];
+                --at;
+            }
+            next[at] = m;
+        }
+        int same = 1; /* :189-195, zip stops at the shorter list */
+        for (uint32_t i = 0; i < n_prev && i < n_next; ++i)
+            if (prev[i] != next[i]) {
+                same = 0;
+                break;
+            }
+        if (same) { /* :196-208 */
+            rc = ORACLE_SPLIT_OK;
+            for (uint32_t i = 0; i < n_next; ++i) {
+                const uint8_t c = next[i];
+                if (!key[c] || cnt[c] == 0) { /* get().unwrap() / min().unwrap() */
+                    rc = ORACLE_SPLIT_ERR_EMPTY;
+                    break;
+                }
+                lo[i] = cmin[c];
+                hi[i] = cmax[c];
+                has[i] = 1;
+            }
+            *n_zones = n_next;
+            break;
+        }
+        memcpy(prev, next, n_next); /* :210 */
+        n_prev = n_next;
+    }
+    free(sum);
+    free(cnt);
+    return rc;
+}
+
+void oracle_invert_depth(uint8_t *depth, size_t n)
+{
+    for (size_t i = 0; i < n; ++i)
+        depth[i] = (uint8_t)(255 - depth[i]);
+}
+
+void oracle_slice(const uint8_t *depth, size_t n, int has_from, uint8_t from, int has_to,
+                  uint8_t to, uint8_t *mask)
+{
+    const uint8_t f = has_from ? from : 0, t = has_to ? to : 255; /* :231-232 */
+    for (size_t i = 0; i < n; ++i)
+        mask[i] = (depth[i] < f || depth[i] > t) ? 0 : 255; /* :237-239 */
+}
+
+int oracle_select_foreground(const uint8_t *depth, size_t n, uint8_t *mask, uint8_t *from,
+                             uint8_t *to)
+{
+    uint8_t lo[256], hi[256], has[256];
+    uint32_t nz = 0;
+    const int rc = oracle_depth_split(depth, n, 2, lo, hi, has, &nz, NULL);
+    if (rc != ORACLE_SPLIT_OK)
+        return rc;
+    if (from)
+        *from = lo[0];
+    if (to)
+        *to = hi[0];
+    oracle_slice(depth, n, has[0], lo[0], has[0], hi[0], mask);
+    return ORACLE_SPLIT_OK;
+}
+
+void oracle_apply_mask(uint8_t *rgba, const uint8_t *mask, size_t n)
+{
+    for (size_t i = 0; i < n; ++i)
+        if (mask[i] == 0)
+            memset(rgba + 4 * i, 0, 4);
+}

@@ -116,6 +116,42 @@ int oracle_sad_rows(const uint8_t *left, const uint8_t *right, uint32_t w, uint3
                     uint32_t win, const uint8_t precision[3], uint32_t row0, uint32_t row1,
                     int threads, uint8_t *raw);
 
+/* ---- consumers of a finished depth map ------------------------------- */
+
+#define ORACLE_SPLIT_OK 0
+#define ORACLE_SPLIT_ERR_STEP (-7)     /* src/depth_image.rs:217: step_by(0) / usize underflow  */
+#define ORACLE_SPLIT_ERR_EMPTY (-8)    /* :203-206: min()/max() of an empty zone -> unwrap panic */
+#define ORACLE_SPLIT_ERR_DIVERGED (-9) /* :210 recursion did not end within the iteration cap   */
+#define ORACLE_SPLIT_ERR_INPUT (-1)    /* :214-215: min() of an empty depth map -> unwrap panic  */
+#define ORACLE_SPLIT_MAX_ITERS 4096
+
+/* DepthImage::depth_split, src/depth_image.rs:162-219, item by item (no histogram shortcut):
+ * 1-D k-means over the depth bytes.  zones < 2 -> one zone (None, None): *n_zones = 1 and
+ * has[0] = 0.  Otherwise zone i is (Some(lo[i]), Some(hi[i])), has[i] = 1, zones ordered by
+ * centroid.  The reference keys its clusters by centroid VALUE (HashMap<u8, Vec<u8>>, :167),
+ * assigns every item to the FIRST nearest centre in list order (min_by, :172-178), takes
+ * floor means with an empty cluster giving 0 (:184-187), sorts them (:188) and compares them
+ * with the previous list pairwise over the shorter length (:189-195).  Inputs on which the
+ * reference panics return one of the error codes above.  lo/hi/has hold up to 256 entries.
+ * Returns the number of assignment passes through *iters (may be NULL). */
+int oracle_depth_split(const uint8_t *depth, size_t n, uint32_t zones, uint8_t *lo, uint8_t *hi,
+                       uint8_t *has, uint32_t *n_zones, uint32_t *iters);
+
+/* DepthImage::invert_depth, src/depth_image.rs:226-228 */
+void oracle_invert_depth(uint8_t *depth, size_t n);
+
+/* DepthImage::slice, src/depth_image.rs:230-247: mask = 255 (MASK_TRUE, mask_image.rs:3)
+ * unless depth < from or depth > to, then 0 (MASK_FALSE, :4); None -> 0 / 255 */
+void oracle_slice(const uint8_t *depth, size_t n, int has_from, uint8_t from, int has_to,
+                  uint8_t to, uint8_t *mask);
+
+/* DepthImage::select_foreground, src/depth_image.rs:221-224: slice(depth_split(2)[0]) */
+int oracle_select_foreground(const uint8_t *depth, size_t n, uint8_t *mask, uint8_t *from,
+                             uint8_t *to);
+
+/* MaskImage::apply_mask, src/mask_image.rs:205-213: RGBA pixel := [0;4] where mask == 0 */
+void oracle_apply_mask(uint8_t *rgba, const uint8_t *mask, size_t n);
+
 /* threads used by ORACLE_THREADS_ALLCORES: every online core, or the count set here (a
  * container's CPU share is usually smaller than the host's core count) */
 void oracle_set_threads(int n);

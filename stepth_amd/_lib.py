@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libstepth_amd.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "stepth_amd.h")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # stepth_status
 OK = 0
@@ -23,6 +23,9 @@ ERR_HIP = -3
 ERR_MAX_ZERO = -4
 ERR_NO_DEVICE = -5
 ERR_OUT_OF_MEMORY = -6
+ERR_SPLIT_STEP = -7
+ERR_SPLIT_EMPTY_ZONE = -8
+ERR_SPLIT_DIVERGED = -9
 
 MODE_RING_FIRST_HIT = 0
 MODE_SAD_WINDOW = 1
@@ -59,6 +62,12 @@ class Stats(C.Structure):
                 ("superblock_steps", C.c_uint64), ("blocks_probed", C.c_uint64)]
 
 
+class Zone(C.Structure):
+    """one (Option<u8>, Option<u8>) of depth_split / slice (reference src/depth_image.rs:162)."""
+    _fields_ = [("has_from", C.c_uint8), ("from_", C.c_uint8), ("has_to", C.c_uint8),
+                ("to", C.c_uint8)]
+
+
 # every symbol include/stepth_amd.h declares: name -> (restype, argtypes)
 _P = C.POINTER
 SYMBOLS = {
@@ -87,6 +96,14 @@ SYMBOLS = {
     "stepth_distance_dot_array_batch": (C.c_int, [C.c_void_p, _P(Image), C.c_void_p, C.c_void_p,
                                                   C.c_size_t, C.c_uint32, C.c_void_p,
                                                   C.c_void_p, C.c_void_p, C.c_void_p]),
+    "stepth_invert_depth": (C.c_int, [C.c_void_p, _P(Image), C.c_uint32]),
+    "stepth_depth_split": (C.c_int, [C.c_void_p, _P(Image), C.c_uint32, _P(Zone), C.c_uint32,
+                                     _P(C.c_uint32)]),
+    "stepth_slice": (C.c_int, [C.c_void_p, _P(Image), _P(Zone), _P(Image), C.c_uint32]),
+    "stepth_select_foreground": (C.c_int, [C.c_void_p, _P(Image), _P(Image), _P(Zone)]),
+    "stepth_select_foreground_batch": (C.c_int, [C.c_void_p, C.c_uint32, _P(Image), _P(Image),
+                                                 _P(Zone), _P(C.c_int), C.c_uint32]),
+    "stepth_apply_mask": (C.c_int, [C.c_void_p, _P(Image), _P(Image), C.c_uint32]),
     "stepth_stats_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "stepth_get_stats": (C.c_int, [C.c_void_p, _P(Stats)]),
     "stepth_kernel_time_enable": (C.c_int, [C.c_void_p, C.c_int]),

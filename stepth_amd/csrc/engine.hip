@@ -18,6 +18,7 @@
 #include "../../include/stepth_amd.h"
 #include "ring_kernels.h"
 #include "sad_kernels.h"
+#include "zone_kernels.h"
 
 using namespace stepth;
 
@@ -52,6 +53,7 @@ struct stepth_engine {
     DevBuf stage_main, stage_add, stage_out, stage_groups;
     DevBuf queries, raw, aux32, aux_pos, aux_found, pending, pending_rec, pending_key;
     DevBuf sad_left, sad_right, gauss_tmp, gauss_io;
+    DevBuf zone_counts, zone_tables; // depth_split: 256 counts and one ZoneTable per frame
     uint32_t *words = nullptr; // layout: kWord* above
     unsigned long long *stats = nullptr; // [ring0_hits, probes]
     DevBuf spiral;                       // block-spiral table + per-chunk complete rings
@@ -434,6 +436,10 @@ const char *stepth_status_string(int status)
     case STEPTH_ERR_MAX_ZERO: return "every distance is zero (reference would divide by zero)";
     case STEPTH_ERR_NO_DEVICE: return "no HIP device";
     case STEPTH_ERR_OUT_OF_MEMORY: return "out of device memory";
+    case STEPTH_ERR_SPLIT_STEP:
+        return "depth range too small for that many zones (reference panics in step_by)";
+    case STEPTH_ERR_SPLIT_EMPTY_ZONE: return "a zone ended up empty (reference panics on unwrap)";
+    case STEPTH_ERR_SPLIT_DIVERGED: return "zone centroids did not settle";
     default: return "unknown status";
     }
 }
@@ -476,7 +482,8 @@ void stepth_engine_destroy(stepth_engine *e)
     (void)hipStreamSynchronize(e->stream);
     for (DevBuf *b : {&e->T, &e->BB, &e->SB, &e->spiral, &e->stage_main, &e->stage_add, &e->stage_out,
                       &e->stage_groups, &e->queries, &e->raw, &e->aux32, &e->aux_pos,
-                      &e->aux_found, &e->pending, &e->pending_rec, &e->pending_key, &e->sad_left, &e->sad_right, &e->gauss_tmp, &e->gauss_io})
+                      &e->aux_found, &e->pending, &e->pending_rec, &e->pending_key, &e->sad_left, &e->sad_right, &e->gauss_tmp, &e->gauss_io,
+                      &e->zone_counts, &e->zone_tables})
         release(*b);
     if (e->words)
         (void)hipFree(e->words);
@@ -1254,5 +1261,7 @@ int stepth_kernel_time_read(stepth_engine *e, double *total_ms, uint64_t *launch
     e->events_used = 0;
     return STEPTH_OK;
 }
+
+#include "zone_entries.h"
 
 } // extern "C"

@@ -6,9 +6,11 @@ the hot path.  All compute of the path runs in the HIP engine through the C-ABI;
 only decodes files (Pillow) and moves numpy arrays.  Rust's
 `io::Error::new(InvalidInput, msg)` becomes `InvalidInput(msg)` with the same messages.
 
-Post-processing consumers of a finished depth map (highlight_depth, depth_split,
-select_foreground, slice, resize) and MaskImage are outside the path (SURVEY.md section 2 rows
-9-10) and are not mirrored here.
+The consumers of a finished depth map that the README's second half uses (Readme.md:18-24,
+SURVEY.md 8f N3) are mirrored too and also run in the engine: `invert_depth`, `depth_split`,
+`slice`, `select_foreground` (src/depth_image.rs:162-247) and `MaskImage.apply_mask`
+(src/mask_image.rs:205-213).  highlight_depth, resize and the rest of MaskImage are outside
+the scope.
 """
 from __future__ import annotations
 
@@ -19,6 +21,8 @@ import numpy as np
 
 from . import _lib as L
 from .engine import Engine, MaxZeroError
+
+MASK_TRUE, MASK_FALSE = 255, 0  # src/mask_image.rs:3-4
 
 _engine: Optional[Engine] = None
 
@@ -163,3 +167,59 @@ class DepthImage:
             self.depth = np.zeros(self.image.shape[:2], np.uint8)
             raise
         self.load_depth(depth)
+
+    # ---- consumers of a finished depth map -------------------------------------------------
+    # src/depth_image.rs:226-228
+    def invert_depth(self, engine: Optional[Engine] = None) -> None:
+        if not self.depth.flags.writeable:  # e.g. a view of a decoded file
+            self.depth = self.depth.copy()
+        (engine or default_engine()).invert_depth(self.depth)
+
+    # src/depth_image.rs:162-219
+    def depth_split(self, zones: int, engine: Optional[Engine] = None):
+        """-> [(min, max), ...] per zone in centroid order; [(None, None)] when zones < 2.
+        Inputs on which the reference panics raise SplitError."""
+        if not 0 <= zones <= 255:
+            raise ValueError("zones is a u8")
+        return (engine or default_engine()).depth_split(self.depth, zones)
+
+    # src/depth_image.rs:230-247
+    def slice(self, from_: Optional[int], to: Optional[int],
+              engine: Optional[Engine] = None) -> "MaskImage":
+        mask = (engine or default_engine()).slice(self.depth, from_, to)
+        return MaskImage(self.image.copy(), mask)
+
+    # src/depth_image.rs:221-224
+    def select_foreground(self, engine: Optional[Engine] = None) -> "MaskImage":
+        mask, _zone = (engine or default_engine()).select_foreground(self.depth)
+        return MaskImage(self.image.copy(), mask)
+
+
+class MaskImage:
+    """`pub struct MaskImage { pub image: RgbaImage, pub mask: GrayImage }`
+    (src/mask_image.rs:6-10) -- only what DepthImage::slice returns and the README flow uses."""
+
+    def __init__(self, image: np.ndarray, mask: Optional[np.ndarray] = None):
+        self.image = image
+        # src/mask_image.rs:17-21: a fresh mask is MASK_TRUE everywhere
+        self.mask = mask if mask is not None else np.full(image.shape[:2], MASK_TRUE, np.uint8)
+
+    def width(self) -> int:
+        return int(self.image.shape[1])
+
+    def height(self) -> int:
+        return int(self.image.shape[0])
+
+    # src/mask_image.rs:205-213
+    def apply_mask(self, engine: Optional[Engine] = None) -> None:
+        if not self.image.flags.writeable:
+            self.image = self.image.copy()
+        (engine or default_engine()).apply_mask(self.image, self.mask)
+
+    # src/mask_image.rs:196-198 (PNG/JPEG by extension, through Pillow)
+    def save(self, path: str) -> None:
+        from PIL import Image
+        img = Image.fromarray(self.image, "RGBA")
+        if path.lower().endswith((".jpg", ".jpeg")):
+            img = img.convert("RGB")
+        img.save(path)

@@ -24,6 +24,10 @@ class MaxZeroError(StepthError):
     """Every distance is 0 -- the reference panics here (src/depth_image.rs:127)."""
 
 
+class SplitError(StepthError):
+    """depth_split input on which the reference panics (src/depth_image.rs:203-217)."""
+
+
 def _is_tensor(a) -> bool:
     return hasattr(a, "data_ptr") and hasattr(a, "is_cuda")
 
@@ -103,7 +107,9 @@ class Engine:
             return
         msg = self._lib.stepth_last_error(self._h).decode() or \
             self._lib.stepth_status_string(st).decode()
-        raise (MaxZeroError if st == L.ERR_MAX_ZERO else StepthError)(st, msg)
+        kind = (MaxZeroError if st == L.ERR_MAX_ZERO else
+                SplitError if L.ERR_SPLIT_DIVERGED <= st <= L.ERR_SPLIT_STEP else StepthError)
+        raise kind(st, msg)
 
     def set_stream(self, hip_stream: int):
         """Run on this hipStream_t handle (0 = HIP's default stream)."""
@@ -279,6 +285,91 @@ class Engine:
         self._check(self._lib.stepth_gaussian_same_size(
             self._h, C.byref(si), C.byref(di), L.FLAG_ASYNC if asynchronous else 0))
         return out
+
+    # ---- consumers of a finished depth map (reference src/depth_image.rs:162-247) ---------
+    def invert_depth(self, depth, asynchronous: bool = False):
+        """stepth_invert_depth: `depth` (numpy [H,W] or CUDA tensor) becomes 255 - depth in place."""
+        di, _k = _describe(depth, (1,), "depth")
+        self._check(self._lib.stepth_invert_depth(self._h, C.byref(di),
+                                                  L.FLAG_ASYNC if asynchronous else 0))
+        return depth
+
+    def depth_split(self, depth, zones: int):
+        """stepth_depth_split -> [(lo, hi), ...] in centroid order; [(None, None)] if zones < 2."""
+        di, _k = _describe(depth, (1,), "depth")
+        out = (L.Zone * 256)()
+        n = C.c_uint32(0)
+        self._check(self._lib.stepth_depth_split(self._h, C.byref(di), int(zones), out, 256,
+                                                 C.byref(n)))
+        return [(z.from_ if z.has_from else None, z.to if z.has_to else None)
+                for z in out[:n.value]]
+
+    def slice(self, depth, from_=None, to=None, out=None, asynchronous: bool = False):
+        """stepth_slice -> mask [H,W] u8 (255 inside [from, to], 0 outside)."""
+        di, _k1 = _describe(depth, (1,), "depth")
+        if out is None:
+            if _is_tensor(depth):
+                import torch
+                out = torch.empty((di.height, di.width), dtype=torch.uint8, device=depth.device)
+            else:
+                out = np.zeros((di.height, di.width), np.uint8)
+        mi, _k2 = _describe(out, (1,), "mask")
+        z = L.Zone(from_ is not None, from_ or 0, to is not None, 255 if to is None else to)
+        self._check(self._lib.stepth_slice(self._h, C.byref(di), C.byref(z), C.byref(mi),
+                                           L.FLAG_ASYNC if asynchronous else 0))
+        return out
+
+    def select_foreground(self, depth, out=None):
+        """stepth_select_foreground -> (mask, (from, to))."""
+        di, _k1 = _describe(depth, (1,), "depth")
+        if out is None:
+            if _is_tensor(depth):
+                import torch
+                out = torch.empty((di.height, di.width), dtype=torch.uint8, device=depth.device)
+            else:
+                out = np.zeros((di.height, di.width), np.uint8)
+        mi, _k2 = _describe(out, (1,), "mask")
+        z = L.Zone()
+        self._check(self._lib.stepth_select_foreground(self._h, C.byref(di), C.byref(mi),
+                                                       C.byref(z)))
+        return out, (z.from_, z.to)
+
+    def select_foreground_batch(self, depths, outs=None, asynchronous: bool = False,
+                                raise_on_error: bool = True):
+        """stepth_select_foreground_batch on CUDA tensors of one shape.
+
+        -> (masks, zones, statuses); zones[f] is (from, to) or None when frame f's split
+        failed (its mask is then left as it was).  Asynchronous calls return (masks, None, None)."""
+        import torch
+        n = len(depths)
+        if outs is None:
+            outs = [torch.empty_like(d) for d in depths]
+        dims = (L.Image * n)()
+        mims = (L.Image * n)()
+        keep = []
+        for f in range(n):
+            dims[f], k1 = _describe(depths[f], (1,), "depth")
+            mims[f], k2 = _describe(outs[f], (1,), "mask")
+            keep += [k1, k2]
+        if asynchronous:
+            self._check(self._lib.stepth_select_foreground_batch(self._h, n, dims, mims, None, None,
+                                                                 L.FLAG_ASYNC))
+            return outs, None, None
+        zs = (L.Zone * n)()
+        st = (C.c_int * n)()
+        rc = self._lib.stepth_select_foreground_batch(self._h, n, dims, mims, zs, st, 0)
+        if rc != L.OK and (raise_on_error or rc > L.ERR_SPLIT_STEP or rc < L.ERR_SPLIT_DIVERGED):
+            self._check(rc)
+        zones = [(zs[f].from_, zs[f].to) if st[f] == 0 else None for f in range(n)]
+        return outs, zones, list(st)
+
+    def apply_mask(self, rgba, mask, asynchronous: bool = False):
+        """stepth_apply_mask: RGBA pixels with mask == 0 become [0,0,0,0], in place."""
+        ri, _k1 = _describe(rgba, (4,), "rgba")
+        mi, _k2 = _describe(mask, (1,), "mask")
+        self._check(self._lib.stepth_apply_mask(self._h, C.byref(ri), C.byref(mi),
+                                                L.FLAG_ASYNC if asynchronous else 0))
+        return rgba
 
     def distance_dot_array_batch(self, array, what, from_xy, max_steps: int, precision):
         """helpers::distance_dot_array for n queries -> (found u8[n], dist u32[n], pos u32[n,2])."""

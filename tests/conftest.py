@@ -42,7 +42,8 @@ def asset():
     """PIL-decoded reference assets, committed as PNG (tests/golden/make_asset_fixtures.py)."""
     from PIL import Image
     load = lambda n: np.asarray(Image.open(os.path.join(GOLDEN, f"asset_{n}.png")))
-    return {"main": load("main"), "additional": load("additional"), "depth": load("depth")}
+    return {"main": load("main"), "additional": load("additional"), "depth": load("depth"),
+            "foreground": load("foreground")}
 
 
 @pytest.fixture(scope="session")

@@ -28,7 +28,7 @@ def declared_functions():
 def test_header_symbols_all_exported_and_bound(lib):
     from stepth_amd import _lib
     names = declared_functions()
-    assert len(names) >= 14
+    assert len(names) >= 25
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/stepth_amd.h but not exported"
     assert sorted(_lib.SYMBOLS) == names, "ctypes binding and header disagree"
@@ -36,10 +36,12 @@ def test_header_symbols_all_exported_and_bound(lib):
 
 def test_abi_version_and_status_strings(lib):
     from stepth_amd import _lib
-    assert lib.stepth_abi_version() == _lib.ABI_VERSION == 1
+    assert lib.stepth_abi_version() == _lib.ABI_VERSION == 2
     # the reference's fixed error text, src/depth_image.rs:45-48
     assert lib.stepth_status_string(_lib.ERR_SIZE_MISMATCH) == b"Sizes don't match"
     assert lib.stepth_status_string(0) == b"ok"
+    for st in (_lib.ERR_SPLIT_STEP, _lib.ERR_SPLIT_EMPTY_ZONE, _lib.ERR_SPLIT_DIVERGED):
+        assert lib.stepth_status_string(st) != b"unknown status"
 
 
 def test_struct_layouts():
@@ -50,6 +52,7 @@ def test_struct_layouts():
     assert C.sizeof(_lib.Image) == 32
     assert C.sizeof(_lib.Params) == 56  # static_assert'ed in csrc/engine.hip
     assert C.sizeof(_lib.Stats) == 56
+    assert C.sizeof(_lib.Zone) == 4
     assert _lib.Params.flags.offset == 40 and _lib.Params.max_steps.offset == 12
 
 
