@@ -277,6 +277,27 @@ def main():
                 "kernel": "sad_search_kernel", "kernel_avg_ms": round(sms / max(sl, 1), 4),
                 "hbm_frac": round(ALGO_BYTES_PER_PIXEL * W * H / (sms / max(sl, 1) * 1e-3) / 1e9
                                   / HBM_PEAK_GBS, 6)}
+        if args.mode == "ring" and world == 1:
+            # README's second half on the depth maps of the last step (Readme.md:18-24):
+            # select_foreground = histogram + depth_split(2) + slice, three launches for all
+            # frames; 1 B read twice + 1 B written per pixel.  Outside the timed region.
+            planes = [depth[f] for f in range(n_frames)]
+            dl = eng.plane_list(planes, (1,), "depth")
+            ml = eng.plane_list([torch.empty_like(p) for p in planes], (1,), "mask")
+            eng.select_foreground_batch(dl, ml, asynchronous=True)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(10):
+                eng.select_foreground_batch(dl, ml, asynchronous=True)
+            e1.record()
+            torch.cuda.synchronize()
+            fms = e0.elapsed_time(e1) / 10
+            out["foreground_tail"] = {
+                "value": round(px_step / (fms * 1e-3) / 1e6, 1), "unit": "Mpixels/s",
+                "workload": f"select_foreground (depth_split(2) + slice) on the step's {n_frames} depth maps",
+                "ms": round(fms, 4), "algorithmic_bytes_per_pixel": 3,
+                "hbm_frac": round(3 * px_step / (fms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         if not args.no_cpu_baseline:
             base, ref_depth = cpu_baseline(frames_np[0], args)
             out["cpu_baseline"] = base

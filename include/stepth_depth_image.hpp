@@ -9,8 +9,10 @@
 // decoder is linked here, other formats fail with "Failed to open image" exactly like an
 // unreadable file does in the reference (src/depth_image.rs:13-17).
 //
-// Post-processing consumers of a finished depth map (highlight_depth, depth_split,
-// select_foreground, slice, resize) and MaskImage are outside the path and not mirrored.
+// The consumers the README's second half uses (Readme.md:18-24) are mirrored too and run in
+// the engine: invert_depth, depth_split, slice, select_foreground (src/depth_image.rs:162-247)
+// and MaskImage{image, mask}::apply_mask / save (src/mask_image.rs:6-10, :196-198, :205-213).
+// highlight_depth, resize and the rest of MaskImage are outside the scope.
 #pragma once
 #include <cstdint>
 #include <cstdio>
@@ -132,6 +134,39 @@ struct DepthOptions {
     bool gaussian_tail = true;        // the same-size Gaussian resample at :133-134
 };
 
+// `Option<u8>` of depth_split's result and slice's arguments
+struct OptionU8 {
+    bool some = false;
+    uint8_t value = 0;
+    static OptionU8 Some(uint8_t v) { return {true, v}; }
+    static OptionU8 None() { return {}; }
+    bool operator==(const OptionU8 &o) const { return some == o.some && (!some || value == o.value); }
+};
+using Zone = std::pair<OptionU8, OptionU8>; // (Option<u8>, Option<u8>), depth_image.rs:162
+
+// `pub struct MaskImage { pub image: RgbaImage, pub mask: GrayImage }`, mask_image.rs:6-10 --
+// only what DepthImage::slice returns and the README flow uses
+class MaskImage {
+  public:
+    Buffer image; // Rgba8
+    Buffer mask;  // Luma8, MASK_TRUE = 255 / MASK_FALSE = 0 (mask_image.rs:3-4)
+
+    uint32_t width() const { return image.width; }
+    uint32_t height() const { return image.height; }
+
+    // src/mask_image.rs:205-213
+    Result apply_mask(stepth_engine *engine)
+    {
+        stepth_image ri{image.data.data(), width(), height(), 4, STEPTH_MEM_HOST, (size_t)width() * 4};
+        stepth_image mi{mask.data.data(), mask.width, mask.height, 1, STEPTH_MEM_HOST, (size_t)mask.width};
+        const int rc = stepth_apply_mask(engine, &ri, &mi, 0);
+        return rc == STEPTH_OK ? Result::Ok() : Result::Err(stepth_last_error(engine));
+    }
+
+    // src/mask_image.rs:196-198 (binary PPM: the RGB planes of `image`)
+    bool save(const std::string &path) const { return detail::write_pnm(path, to_rgb8(image)); }
+};
+
 // `pub struct DepthImage { pub image: RgbaImage, pub depth: GrayImage }`, depth_image.rs:6-10
 class DepthImage {
   public:
@@ -230,6 +265,68 @@ class DepthImage {
             return Result::Err(rc == STEPTH_ERR_SIZE_MISMATCH ? "Sizes don't match"
                                                               : stepth_last_error(engine));
         return load_depth(std::move(out)); // :135
+    }
+
+    // ---- consumers of a finished depth map ------------------------------------------------
+    // src/depth_image.rs:226-228
+    Result invert_depth(stepth_engine *engine)
+    {
+        const stepth_image di = depth_view();
+        const int rc = stepth_invert_depth(engine, &di, 0);
+        return rc == STEPTH_OK ? Result::Ok() : Result::Err(stepth_last_error(engine));
+    }
+
+    // src/depth_image.rs:162-219.  Where the reference panics (:203-217) this returns Err with
+    // the status text and leaves `zones` empty.
+    Result depth_split(stepth_engine *engine, uint8_t n_zones, std::vector<Zone> &zones) const
+    {
+        zones.clear();
+        stepth_zone z[256];
+        uint32_t n = 0;
+        const stepth_image di = depth_view();
+        const int rc = stepth_depth_split(engine, &di, n_zones, z, 256, &n);
+        if (rc != STEPTH_OK)
+            return Result::Err(rc <= STEPTH_ERR_SPLIT_STEP && rc >= STEPTH_ERR_SPLIT_DIVERGED
+                                   ? stepth_status_string(rc)
+                                   : stepth_last_error(engine));
+        for (uint32_t i = 0; i < n; ++i)
+            zones.push_back({z[i].has_from ? OptionU8::Some(z[i].from) : OptionU8::None(),
+                             z[i].has_to ? OptionU8::Some(z[i].to) : OptionU8::None()});
+        return Result::Ok();
+    }
+
+    // src/depth_image.rs:230-247
+    Result slice(stepth_engine *engine, OptionU8 from, OptionU8 to, MaskImage &out) const
+    {
+        out.image = image; // :243 self.image.clone()
+        out.mask = Buffer{width(), height(), 1, std::vector<uint8_t>((size_t)width() * height(), 0)};
+        const stepth_zone range{(uint8_t)from.some, from.value, (uint8_t)to.some, to.value};
+        const stepth_image di = depth_view();
+        stepth_image mi{out.mask.data.data(), width(), height(), 1, STEPTH_MEM_HOST, (size_t)width()};
+        const int rc = stepth_slice(engine, &di, &range, &mi, 0);
+        return rc == STEPTH_OK ? Result::Ok() : Result::Err(stepth_last_error(engine));
+    }
+
+    // src/depth_image.rs:221-224
+    Result select_foreground(stepth_engine *engine, MaskImage &out) const
+    {
+        out.image = image;
+        out.mask = Buffer{width(), height(), 1, std::vector<uint8_t>((size_t)width() * height(), 0)};
+        const stepth_image di = depth_view();
+        stepth_image mi{out.mask.data.data(), width(), height(), 1, STEPTH_MEM_HOST, (size_t)width()};
+        const int rc = stepth_select_foreground(engine, &di, &mi, nullptr);
+        if (rc == STEPTH_OK)
+            return Result::Ok();
+        return Result::Err(rc <= STEPTH_ERR_SPLIT_STEP && rc >= STEPTH_ERR_SPLIT_DIVERGED
+                               ? stepth_status_string(rc)
+                               : stepth_last_error(engine));
+    }
+
+  private:
+    stepth_image depth_view() const
+    {
+        return stepth_image{depth.data.data(), depth.width, depth.height, 1, STEPTH_MEM_HOST,
+                            (size_t)depth.width};
     }
 };
 

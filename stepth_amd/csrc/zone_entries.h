@@ -59,7 +59,12 @@ static int split_device(stepth_engine *e, uint32_t nf, const uint8_t *const *pla
         a.src[f] = planes[f];
     plane_shape(w, h, stride, stride, a);
     HIP_TRY(e, hipMemsetAsync(e->zone_counts.p, 0, (size_t)nf * 256 * sizeof(uint32_t), e->stream));
-    hipLaunchKernelGGL(depth_histogram_kernel, plane_grid(a, nf), dim3(256), 0, e->stream, a,
+    // every workgroup ends with up to 256 atomics on the frame's counts, and atomics on one
+    // address serialise in L2: about a thousand workgroups in all keep that tail short
+    const uint64_t segs = (uint64_t)((a.W + 15u) >> 4) * a.H;
+    const uint32_t per_frame = std::max<uint32_t>(1024u / nf, 8u);
+    const dim3 hgrid((uint32_t)std::min<uint64_t>((segs + 256 * kHistUnroll - 1) / (256 * kHistUnroll), per_frame), nf);
+    hipLaunchKernelGGL(depth_histogram_kernel, hgrid, dim3(256), 0, e->stream, a,
                        static_cast<uint32_t *>(e->zone_counts.p));
     hipLaunchKernelGGL(depth_split_kernel, dim3(nf), dim3(256), 0, e->stream,
                        static_cast<const uint32_t *>(e->zone_counts.p), zones,

@@ -56,12 +56,21 @@ __device__ __forceinline__ Seg seg_of(uint32_t s, uint32_t W, uint32_t spr)
     return g;
 }
 
-constexpr uint32_t kHistReplicas = 8;
+constexpr uint32_t kHistReplicas = 32; // one per LDS bank of a 32-bit access
+constexpr uint32_t kHistUnroll = 4;    // 16-byte loads in flight per lane
 
-// counts[frame][256] += histogram of the frame's bytes.  LDS holds 8 copies of the table
-// (lane & 7 picks one) and every lane run-length-merges its 16 bytes first, so a flat region
-// (depth maps are mostly flat: 71 % zeros on the asset) costs one LDS atomic per lane per trip
-// instead of sixteen on one address.
+// counts[frame][256] += histogram of the frame's bytes.  LDS holds 32 interleaved copies of
+// the table, word (v * 32 + lane % 32): a 32-bit LDS access is banked by (word % 32) within
+// each half-wave, so every lane of a half owns its bank whatever the data looks like (depth
+// maps are mostly flat: 71 % zeros on the asset) and ds_add_u32 never conflicts.
+__device__ __forceinline__ void hist_word(uint32_t *mine, uint32_t w)
+{
+    atomicAdd(&mine[(w & 255u) * kHistReplicas], 1u);
+    atomicAdd(&mine[((w >> 8) & 255u) * kHistReplicas], 1u);
+    atomicAdd(&mine[((w >> 16) & 255u) * kHistReplicas], 1u);
+    atomicAdd(&mine[(w >> 24) * kHistReplicas], 1u);
+}
+
 __global__ __launch_bounds__(256) void depth_histogram_kernel(PlaneArgs a, uint32_t *counts)
 {
     __shared__ uint32_t s_h[kHistReplicas * 256];
@@ -70,37 +79,41 @@ __global__ __launch_bounds__(256) void depth_histogram_kernel(PlaneArgs a, uint3
     __syncthreads();
     const uint32_t f = blockIdx.y;
     const uint8_t *src = a.src[f];
-    uint32_t *mine = s_h + (threadIdx.x & (kHistReplicas - 1)) * 256;
+    uint32_t *mine = s_h + (threadIdx.x & (kHistReplicas - 1));
     const uint32_t spr = segs_per_row(a.W), total = spr * a.H;
-    for (uint32_t s = blockIdx.x * 256 + threadIdx.x; s < total; s += gridDim.x * 256) {
-        const Seg g = seg_of(s, a.W, spr);
-        const uint8_t *p = src + (size_t)g.row * a.src_stride + g.x;
-        if (g.n == 16 && ((uintptr_t)p & 15u) == 0) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(p);
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-            uint32_t cur = w[0] & 255u, cnt = 0;
+    const uint32_t step = gridDim.x * 256;
+    for (uint32_t s0 = blockIdx.x * 256 + threadIdx.x; s0 < total; s0 += step * kHistUnroll) {
+        uint4 v[kHistUnroll];
+        uint32_t fast = 0; // bit u: segment u was loaded as one aligned 16-byte word
 #pragma unroll
-            for (uint32_t k = 0; k < 16; ++k) {
-                const uint32_t b = (w[k >> 2] >> ((k & 3) * 8)) & 255u;
-                if (b == cur) {
-                    ++cnt;
+        for (uint32_t u = 0; u < kHistUnroll; ++u) {
+            const uint32_t s = s0 + u * step;
+            if (s < total) {
+                const Seg g = seg_of(s, a.W, spr);
+                const uint8_t *p = src + (size_t)g.row * a.src_stride + g.x;
+                if (g.n == 16 && ((uintptr_t)p & 15u) == 0) {
+                    v[u] = *reinterpret_cast<const uint4 *>(p);
+                    fast |= 1u << u;
                 } else {
-                    atomicAdd(&mine[cur], cnt);
-                    cur = b;
-                    cnt = 1;
+                    for (uint32_t k = 0; k < g.n; ++k)
+                        atomicAdd(&mine[(uint32_t)p[k] * kHistReplicas], 1u);
                 }
             }
-            atomicAdd(&mine[cur], cnt);
-        } else {
-            for (uint32_t k = 0; k < g.n; ++k)
-                atomicAdd(&mine[p[k]], 1u);
         }
+#pragma unroll
+        for (uint32_t u = 0; u < kHistUnroll; ++u)
+            if (fast & (1u << u)) {
+                hist_word(mine, v[u].x);
+                hist_word(mine, v[u].y);
+                hist_word(mine, v[u].z);
+                hist_word(mine, v[u].w);
+            }
     }
     __syncthreads();
-    uint32_t sum = 0;
-#pragma unroll
+    uint32_t sum = 0; // bin threadIdx.x; start at a different copy per lane: no bank conflicts
+#pragma unroll 8
     for (uint32_t r = 0; r < kHistReplicas; ++r)
-        sum += s_h[r * 256 + threadIdx.x];
+        sum += s_h[threadIdx.x * kHistReplicas + ((r + threadIdx.x) & (kHistReplicas - 1))];
     if (sum)
         atomicAdd(&counts[f * 256 + threadIdx.x], sum);
 }
@@ -112,7 +125,7 @@ __global__ __launch_bounds__(256) void depth_split_kernel(const uint32_t *counts
                                                           ZoneTable *tables)
 {
     __shared__ uint8_t s_prev[256], s_next[256];
-    __shared__ uint32_t s_nprev, s_min, s_max, s_done;
+    __shared__ uint32_t s_nprev, s_nnext, s_min, s_max, s_differ, s_empty, s_wave_total[4];
     __shared__ unsigned long long s_sum[256], s_cnt[256];
     __shared__ uint32_t s_key[256], s_cmin[256], s_cmax[256], s_mean_count[256];
     const uint32_t v = threadIdx.x;
@@ -121,7 +134,6 @@ __global__ __launch_bounds__(256) void depth_split_kernel(const uint32_t *counts
     if (v == 0) {
         s_min = 255u;
         s_max = 0u;
-        s_done = 0u;
     }
     __syncthreads();
     if (mine) { // :214-215
@@ -129,25 +141,25 @@ __global__ __launch_bounds__(256) void depth_split_kernel(const uint32_t *counts
         atomicMax(&s_max, v);
     }
     __syncthreads();
-    if (v == 0) {
+    {
         // :217  ((img_max - img_min) / (zones - 1)) as usize - 1, then step_by(step): a
         // quotient of 0 underflows and of 1 gives step_by(0); both panic in the reference
-        const uint32_t q = (s_max - s_min) / (zones - 1u);
-        if (s_max < s_min || q < 2u) {
-            out->status = kSplitErrStep;
-            out->n = 0;
-            out->iters = 0;
-            s_done = 1u;
-        } else {
-            uint32_t n = 0;
-            for (uint32_t c = s_min; c < s_max; c += q - 1u) // :216-218, img_max exclusive
-                s_prev[n++] = (uint8_t)c;
-            s_nprev = n;
+        const uint32_t lo = s_min, hi = s_max;
+        const uint32_t q = hi >= lo ? (hi - lo) / (zones - 1u) : 0u;
+        if (q < 2u) {
+            if (v == 0) {
+                out->status = kSplitErrStep;
+                out->n = 0;
+                out->iters = 0;
+            }
+            return;
         }
+        const uint32_t step = q - 1u, n = (hi - lo + step - 1u) / step; // :216-218, hi exclusive
+        if (v < n)
+            s_prev[v] = (uint8_t)(lo + v * step);
+        if (v == 0)
+            s_nprev = n;
     }
-    __syncthreads();
-    if (s_done)
-        return;
     for (uint32_t it = 1;; ++it) {
         s_sum[v] = 0;
         s_cnt[v] = 0;
@@ -156,6 +168,10 @@ __global__ __launch_bounds__(256) void depth_split_kernel(const uint32_t *counts
         s_cmax[v] = 0u;
         s_mean_count[v] = 0;
         __syncthreads();
+        if (v == 0) { // read by everyone at the end of the previous trip, before that barrier
+            s_differ = 0u;
+            s_empty = 0u;
+        }
         const uint32_t np = s_nprev;
         if (v < np)
             s_key[s_prev[v]] = 1u; // :167-170
@@ -180,46 +196,62 @@ __global__ __launch_bounds__(256) void depth_split_kernel(const uint32_t *counts
             atomicAdd(&s_mean_count[(uint32_t)(s_sum[v] / (c ? c : 1ull))], 1u);
         }
         __syncthreads();
-        if (v == 0) {
-            uint32_t n = 0; // :188 sort = walk the mean values upwards
-            for (uint32_t m = 0; m < 256; ++m)
-                for (uint32_t r = s_mean_count[m]; r; --r)
-                    s_next[n++] = (uint8_t)m;
-            bool same = true; // :189-195, zip stops at the shorter list
-            for (uint32_t i = 0; i < n && i < np; ++i)
-                if (s_prev[i] != s_next[i]) {
-                    same = false;
-                    break;
-                }
-            if (same) { // :196-208
-                int status = 0;
-                for (uint32_t i = 0; i < n; ++i) {
-                    const uint32_t c = s_next[i];
-                    if (!s_key[c] || s_cnt[c] == 0) { // unwrap() of None panics
-                        status = kSplitErrEmpty;
-                        break;
-                    }
-                    out->lo[i] = (uint8_t)s_cmin[c];
-                    out->hi[i] = (uint8_t)s_cmax[c];
-                }
-                out->status = status;
-                out->n = status ? 0 : n;
+        {
+            // :188 sort: mean value v goes to positions [before, before + count) of the list;
+            // `before` = exclusive prefix sum of the counts (wave scan + 4 wave totals)
+            const uint32_t count = s_mean_count[v], lane = v & 63u;
+            uint32_t incl = count;
+#pragma unroll
+            for (uint32_t off = 1; off < 64; off <<= 1) {
+                const uint32_t up = __shfl_up(incl, off);
+                if (lane >= off)
+                    incl += up;
+            }
+            if (lane == 63u)
+                s_wave_total[v >> 6] = incl;
+            __syncthreads();
+            uint32_t before = incl - count;
+            for (uint32_t w = 0; w < (v >> 6); ++w)
+                before += s_wave_total[w];
+            for (uint32_t r = 0; r < count; ++r)
+                s_next[before + r] = (uint8_t)v;
+            if (v == 255u)
+                s_nnext = before + count;
+        }
+        __syncthreads();
+        const uint32_t n = s_nnext;
+        if (v < n && v < np && s_prev[v] != s_next[v]) // :189-195, zip stops at the shorter list
+            s_differ = 1u;
+        __syncthreads();
+        if (!s_differ) { // :196-208
+            if (v < n) {
+                const uint32_t c = s_next[v];
+                if (!s_key[c] || s_cnt[c] == 0) // unwrap() of None panics
+                    s_empty = 1u;
+                out->lo[v] = (uint8_t)s_cmin[c];
+                out->hi[v] = (uint8_t)s_cmax[c];
+            }
+            __syncthreads();
+            if (v == 0) {
+                out->status = s_empty ? kSplitErrEmpty : 0;
+                out->n = s_empty ? 0u : n;
                 out->iters = it;
-                s_done = 1u;
-            } else if (it >= kSplitMaxIters) {
+            }
+            return;
+        }
+        if (it >= kSplitMaxIters) {
+            if (v == 0) {
                 out->status = kSplitErrDiverged;
                 out->n = 0;
                 out->iters = it;
-                s_done = 1u;
-            } else {
-                for (uint32_t i = 0; i < n; ++i) // :210
-                    s_prev[i] = s_next[i];
-                s_nprev = n;
             }
-        }
-        __syncthreads();
-        if (s_done)
             return;
+        }
+        if (v < n) // :210
+            s_prev[v] = s_next[v];
+        if (v == 0)
+            s_nprev = n;
+        // the barrier after the clears at the top of the loop orders these writes
     }
 }
 

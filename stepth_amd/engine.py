@@ -73,6 +73,16 @@ GROUP_DTYPE = np.dtype([("x", "<u4"), ("y", "<u4"), ("w", "<u4"), ("h", "<u4"),
                         ("value", "u1", (3,)), ("pad", "u1")])
 
 
+class PlaneList:
+    """ctypes descriptions of a list of CUDA tensors (built once, reused by batch calls)."""
+
+    def __init__(self, tensors, channels=(1,), name: str = "plane"):
+        self.tensors = list(tensors)
+        self.images = (L.Image * len(self.tensors))()
+        for f, t in enumerate(self.tensors):
+            self.images[f], _keep = _describe(t, channels, name)
+
+
 class Engine:
     """One engine per device/stream (stepth_engine_create)."""
 
@@ -334,23 +344,29 @@ class Engine:
                                                        C.byref(z)))
         return out, (z.from_, z.to)
 
+    @staticmethod
+    def plane_list(tensors, channels=(1,), name: str = "plane") -> "PlaneList":
+        """Describes a list of CUDA tensors once, for repeated batch calls on the same buffers."""
+        return PlaneList(tensors, channels, name)
+
     def select_foreground_batch(self, depths, outs=None, asynchronous: bool = False,
                                 raise_on_error: bool = True):
-        """stepth_select_foreground_batch on CUDA tensors of one shape.
+        """stepth_select_foreground_batch on CUDA tensors of one shape (lists of tensors, or
+        PlaneList objects from plane_list() when the same buffers are used call after call).
 
         -> (masks, zones, statuses); zones[f] is (from, to) or None when frame f's split
         failed (its mask is then left as it was).  Asynchronous calls return (masks, None, None)."""
         import torch
-        n = len(depths)
+        if not isinstance(depths, PlaneList):
+            depths = PlaneList(depths, (1,), "depth")
         if outs is None:
-            outs = [torch.empty_like(d) for d in depths]
-        dims = (L.Image * n)()
-        mims = (L.Image * n)()
-        keep = []
-        for f in range(n):
-            dims[f], k1 = _describe(depths[f], (1,), "depth")
-            mims[f], k2 = _describe(outs[f], (1,), "mask")
-            keep += [k1, k2]
+            outs = [torch.empty_like(d) for d in depths.tensors]
+        if not isinstance(outs, PlaneList):
+            outs = PlaneList(outs, (1,), "mask")
+        n = len(depths.tensors)
+        if len(outs.tensors) != n:
+            raise ValueError("one mask per depth map")
+        dims, mims, outs = depths.images, outs.images, outs.tensors
         if asynchronous:
             self._check(self._lib.stepth_select_foreground_batch(self._h, n, dims, mims, None, None,
                                                                  L.FLAG_ASYNC))

@@ -67,3 +67,34 @@ def test_cpp_mirror_readme_flow_matches_oracle(oracle, asset, tmp_path):
     r = subprocess.run([CLI, str(tmp_path / "missing.ppm"), str(tmp_path / "additional.ppm"),
                         str(out)], capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "Failed to open image" in r.stderr
+
+
+def read_ppm(path):
+    data = open(path, "rb").read()
+    parts = data.split(b"\n", 3)
+    assert parts[0] == b"P6" and parts[2] == b"255"
+    w, h = map(int, parts[1].split())
+    return np.frombuffer(parts[3], np.uint8).reshape(h, w, 3)
+
+
+@pytest.mark.gpu
+def test_cpp_mirror_readme_second_half_matches_oracle(oracle, asset, tmp_path):
+    """Readme.md:18-24: open_depth, invert_depth, select_foreground, apply_mask, save."""
+    write_pnm(tmp_path / "main.ppm", asset["main"])
+    write_pnm(tmp_path / "depth.pgm", asset["depth"])
+    out = tmp_path / "foreground.ppm"
+    r = subprocess.run([CLI, "--foreground", str(tmp_path / "main.ppm"), str(tmp_path / "depth.pgm"),
+                        str(out), "--zones", "5"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    inv = oracle.invert_depth(asset["depth"])
+    want_zones = oracle.depth_split(inv, 5)["zones"]
+    got_zones = [tuple(map(int, l.split()[1:])) for l in r.stdout.splitlines() if l.startswith("zone")]
+    assert got_zones == want_zones
+    mask = oracle.select_foreground(inv)["mask"]
+    rgba = np.concatenate([asset["main"], np.full(asset["main"].shape[:2] + (1,), 255, np.uint8)], 2)
+    np.testing.assert_array_equal(read_ppm(out), oracle.apply_mask(rgba, mask)[..., :3])
+    # a flat depth map: the reference panics in depth_split (src/depth_image.rs:217)
+    write_pnm(tmp_path / "flat.pgm", np.full(asset["depth"].shape, 9, np.uint8))
+    r = subprocess.run([CLI, "--foreground", str(tmp_path / "main.ppm"), str(tmp_path / "flat.pgm"),
+                        str(out)], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "step_by" in r.stderr
