@@ -165,8 +165,14 @@ int stepth_depth_from_additional(stepth_engine *engine, const stepth_image *main
  * small frame or row strip cannot fill the GPU -- the cost of a query varies by two orders of
  * magnitude and one heavy query is a ~100 us critical path -- so callers with several frames
  * in flight (video, row-strip sharding of many frames) should batch them.
- *   - ring mode, uniform 1x1 tiles (one group per pixel), every frame the same sizes/strides,
- *     all images in device memory; params (rows, row pattern, flags) apply to every frame;
+ *   - ring mode, uniform 1x1 tiles (one group per pixel), every frame the same sizes; params
+ *     (rows, row pattern, flags) apply to every frame;
+ *   - every image in device memory (same strides for every frame), or every image in host
+ *     memory (what a caller holding decoded images in RAM has, src/depth_image.rs:8-9, :96).
+ *     Host batches are synchronous and pipelined: chunks of frames are uploaded on a copy
+ *     stream while the previous chunk's kernels run and the one before downloads, so the PCIe
+ *     transfers hide behind the kernels; page-locked memory (stepth_host_alloc) makes the
+ *     copies fully asynchronous;
  *   - n_frames is not limited (the engine works through it in chunks of 32);
  *   - max_out: n_frames words, device memory with STEPTH_FLAG_ASYNC, host memory otherwise
  *     (synchronous calls return STEPTH_ERR_MAX_ZERO if ANY frame's max is 0).
@@ -175,6 +181,14 @@ int stepth_depth_from_additional_batch(stepth_engine *engine, uint32_t n_frames,
                                        const stepth_image *mains, const stepth_image *additionals,
                                        const stepth_params *params, const stepth_image *depths,
                                        uint32_t *max_out);
+
+/*
+ * Page-locked host memory for image buffers handed to the engine as STEPTH_MEM_HOST (decode
+ * straight into it): uploads and downloads of such memory run at full PCIe rate and overlap
+ * the kernels.  Free with stepth_host_free.  Ordinary (pageable) memory works everywhere too.
+ */
+int stepth_host_alloc(void **out, size_t bytes);
+void stepth_host_free(void *ptr);
 
 /*
  * PASS 2 on a strip, src/depth_image.rs:125-129: data[r][c] = data[r][c]*255/max (u64

@@ -54,6 +54,11 @@ struct stepth_engine {
     DevBuf queries, raw, aux32, aux_pos, aux_found, pending, pending_rec, pending_key;
     DevBuf sad_left, sad_right, gauss_tmp, gauss_io;
     DevBuf zone_counts, zone_tables; // depth_split: 256 counts and one ZoneTable per frame
+    // host-image batches: two slots of device staging, copy streams and events (batch_host)
+    DevBuf pipe_main[2], pipe_add[2], pipe_out[2], pipe_max;
+    hipStream_t copy_in = nullptr, copy_out = nullptr;
+    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_compute[2] = {nullptr, nullptr},
+               ev_out[2] = {nullptr, nullptr};
     uint32_t *words = nullptr; // layout: kWord* above
     unsigned long long *stats = nullptr; // [ring0_hits, probes]
     DevBuf spiral;                       // block-spiral table + per-chunk complete rings
@@ -483,8 +488,16 @@ void stepth_engine_destroy(stepth_engine *e)
     for (DevBuf *b : {&e->T, &e->BB, &e->SB, &e->spiral, &e->stage_main, &e->stage_add, &e->stage_out,
                       &e->stage_groups, &e->queries, &e->raw, &e->aux32, &e->aux_pos,
                       &e->aux_found, &e->pending, &e->pending_rec, &e->pending_key, &e->sad_left, &e->sad_right, &e->gauss_tmp, &e->gauss_io,
-                      &e->zone_counts, &e->zone_tables})
+                      &e->zone_counts, &e->zone_tables, &e->pipe_main[0], &e->pipe_main[1],
+                      &e->pipe_add[0], &e->pipe_add[1], &e->pipe_out[0], &e->pipe_out[1], &e->pipe_max})
         release(*b);
+    for (hipEvent_t ev : {e->ev_in[0], e->ev_in[1], e->ev_compute[0], e->ev_compute[1], e->ev_out[0],
+                          e->ev_out[1]})
+        if (ev)
+            (void)hipEventDestroy(ev);
+    for (hipStream_t st : {e->copy_in, e->copy_out})
+        if (st)
+            (void)hipStreamDestroy(st);
     if (e->words)
         (void)hipFree(e->words);
     if (e->stats)
@@ -496,6 +509,25 @@ void stepth_engine_destroy(stepth_engine *e)
     if (e->own_stream)
         (void)hipStreamDestroy(e->own_stream);
     delete e;
+}
+
+int stepth_host_alloc(void **out, size_t bytes)
+{
+    if (!out || bytes == 0)
+        return STEPTH_ERR_BAD_ARG;
+    *out = nullptr;
+    const hipError_t r = hipHostMalloc(out, bytes, hipHostMallocDefault);
+    if (r == hipErrorOutOfMemory)
+        return STEPTH_ERR_OUT_OF_MEMORY;
+    if (r == hipErrorNoDevice || r == hipErrorInvalidDevice)
+        return STEPTH_ERR_NO_DEVICE;
+    return r == hipSuccess ? STEPTH_OK : STEPTH_ERR_HIP;
+}
+
+void stepth_host_free(void *ptr)
+{
+    if (ptr)
+        (void)hipHostFree(ptr);
 }
 
 int stepth_engine_set_stream(stepth_engine *e, void *hip_stream)
@@ -851,6 +883,10 @@ int stepth_depth_from_additional(stepth_engine *e, const stepth_image *main_im,
     return STEPTH_OK;
 }
 
+static int batch_host(stepth_engine *e, uint32_t n_frames, const stepth_image *mains,
+                      const stepth_image *adds, const stepth_params &p, const stepth_image *depths,
+                      uint32_t *max_out);
+
 int stepth_depth_from_additional_batch(stepth_engine *e, uint32_t n_frames,
                                        const stepth_image *mains, const stepth_image *adds,
                                        const stepth_params *pp, const stepth_image *depths,
@@ -867,13 +903,27 @@ int stepth_depth_from_additional_batch(stepth_engine *e, uint32_t n_frames,
         (p.flags & STEPTH_FLAG_GAUSSIAN_TAIL))
         return fail(e, STEPTH_ERR_BAD_ARG,
                     "batch: ring mode with 1x1 tiles only, no Gaussian tail");
+    uint32_t n_host = 0;
     for (uint32_t f = 0; f < n_frames; ++f) {
         TRY(check_image(e, &mains[f], "main", 3, 4));
         TRY(check_image(e, &adds[f], "additional", 3, 3));
         TRY(check_image(e, &depths[f], "depth", 1, 1));
+        n_host += (mains[f].memory == STEPTH_MEM_HOST) + (adds[f].memory == STEPTH_MEM_HOST) +
+                  (depths[f].memory == STEPTH_MEM_HOST);
+        if (mains[f].width != mains[0].width || mains[f].height != mains[0].height ||
+            mains[f].channels != mains[0].channels || adds[f].width != adds[0].width ||
+            adds[f].height != adds[0].height)
+            return fail(e, STEPTH_ERR_BAD_ARG, "batch: frame %u differs in size", f);
+        if (depths[f].width != mains[0].width || depths[f].height != mains[0].height)
+            return fail(e, STEPTH_ERR_SIZE_MISMATCH, "Sizes don't match");
+    }
+    if (n_host == 3 * n_frames) // every image in host memory: staged and pipelined
+        return batch_host(e, n_frames, mains, adds, p, depths, max_out);
+    for (uint32_t f = 0; f < n_frames; ++f) {
         if (mains[f].memory != STEPTH_MEM_DEVICE || adds[f].memory != STEPTH_MEM_DEVICE ||
             depths[f].memory != STEPTH_MEM_DEVICE)
-            return fail(e, STEPTH_ERR_BAD_ARG, "batch: images must be device memory");
+            return fail(e, STEPTH_ERR_BAD_ARG,
+                        "batch: images must be all device memory or all host memory");
         if (mains[f].width != mains[0].width || mains[f].height != mains[0].height ||
             mains[f].channels != mains[0].channels || mains[f].stride != mains[0].stride ||
             adds[f].width != adds[0].width || adds[f].height != adds[0].height ||
@@ -998,6 +1048,111 @@ int stepth_depth_from_additional_batch(stepth_engine *e, uint32_t n_frames,
         }
     }
     if (!async && any_zero && !raw_only)
+        return fail(e, STEPTH_ERR_MAX_ZERO, "a frame's distances are all 0; its output is all zero");
+    return STEPTH_OK;
+}
+
+// Host-memory batch (what a caller holding decoded images in RAM has, src/depth_image.rs:8-9,
+// :96): frames go through two slots of device staging in chunks, uploads on their own stream,
+// downloads on another, so the upload of chunk k+1 and the download of chunk k-1 overlap the
+// kernels of chunk k.  Page-locked caller memory (stepth_host_alloc) makes
+// the copies truly asynchronous; pageable memory still overlaps because the kernels of the
+// previous chunk are already enqueued when the host blocks in the next copy.
+static int batch_host(stepth_engine *e, uint32_t n_frames, const stepth_image *mains,
+                      const stepth_image *adds, const stepth_params &p, const stepth_image *depths,
+                      uint32_t *max_out)
+{
+    if (p.flags & STEPTH_FLAG_ASYNC)
+        return fail(e, STEPTH_ERR_BAD_ARG, "STEPTH_FLAG_ASYNC needs device memory everywhere");
+    HIP_TRY(e, hipSetDevice(e->device));
+    if (!e->copy_in) {
+        HIP_TRY(e, hipStreamCreateWithFlags(&e->copy_in, hipStreamNonBlocking));
+        HIP_TRY(e, hipStreamCreateWithFlags(&e->copy_out, hipStreamNonBlocking));
+        for (int s = 0; s < 2; ++s) {
+            HIP_TRY(e, hipEventCreateWithFlags(&e->ev_in[s], hipEventDisableTiming));
+            HIP_TRY(e, hipEventCreateWithFlags(&e->ev_compute[s], hipEventDisableTiming));
+            HIP_TRY(e, hipEventCreateWithFlags(&e->ev_out[s], hipEventDisableTiming));
+        }
+    }
+    const uint32_t W = mains[0].width, H = mains[0].height, mch = mains[0].channels;
+    const uint32_t Wa = adds[0].width, Ha = adds[0].height;
+    const size_t mpitch = ((size_t)W * mch + 15) & ~(size_t)15, apitch = ((size_t)Wa * 3 + 15) & ~(size_t)15,
+                 opitch = ((size_t)W + 15) & ~(size_t)15;
+    const size_t mbytes = mpitch * H, abytes = apitch * Ha, obytes = opitch * H;
+    // chunk: about 64 MB of input, at most 8 frames (the kernels are near their batched
+    // efficiency from 4 frames on and a small chunk starts the pipeline sooner)
+    const uint32_t chunk = (uint32_t)std::max<size_t>(
+        1, std::min<size_t>({(size_t)8, (size_t)n_frames, ((size_t)64 << 20) / (mbytes + abytes) + 1}));
+    for (int s = 0; s < 2; ++s) {
+        TRY(reserve(e, e->pipe_main[s], mbytes * chunk));
+        TRY(reserve(e, e->pipe_add[s], abytes * chunk));
+        TRY(reserve(e, e->pipe_out[s], obytes * chunk));
+    }
+    TRY(reserve(e, e->pipe_max, (size_t)n_frames * 4));
+    uint32_t *d_max = static_cast<uint32_t *>(e->pipe_max.p);
+    stepth_params dp = p;
+    dp.flags |= STEPTH_FLAG_ASYNC;
+    // the first upload and the last download cannot hide behind kernels: start with two
+    // frames and double up to `chunk`, end symmetric (short last chunks come by themselves)
+    std::vector<std::pair<uint32_t, uint32_t>> chunks; // (first frame, frames)
+    for (uint32_t f0 = 0, c = std::min(2u, chunk); f0 < n_frames;) {
+        const uint32_t nf = std::min(c, n_frames - f0);
+        chunks.emplace_back(f0, nf);
+        f0 += nf;
+        c = std::min(chunk, c * 2u);
+    }
+    const uint32_t n_chunks = (uint32_t)chunks.size();
+    std::vector<stepth_image> dm(chunk), da(chunk), dd(chunk);
+
+    auto download = [&](uint32_t k) -> int { // chunk k's depth maps -> caller memory
+        const uint32_t s = k & 1u, f0 = chunks[k].first, nf = chunks[k].second;
+        HIP_TRY(e, hipStreamWaitEvent(e->copy_out, e->ev_compute[s], 0));
+        for (uint32_t f = 0; f < nf; ++f)
+            HIP_TRY(e, hipMemcpy2DAsync(const_cast<void *>(depths[f0 + f].data), depths[f0 + f].stride,
+                                        static_cast<uint8_t *>(e->pipe_out[s].p) + obytes * f, opitch, W, H,
+                                        hipMemcpyDeviceToHost, e->copy_out));
+        HIP_TRY(e, hipEventRecord(e->ev_out[s], e->copy_out));
+        return STEPTH_OK;
+    };
+
+    for (uint32_t k = 0; k < n_chunks; ++k) {
+        const uint32_t s = k & 1u, f0 = chunks[k].first, nf = chunks[k].second;
+        if (k >= 2) { // slot s: inputs consumed by chunk k-2's kernels, outputs by its download
+            HIP_TRY(e, hipStreamWaitEvent(e->copy_in, e->ev_compute[s], 0));
+            HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_out[s], 0));
+        }
+        for (uint32_t f = 0; f < nf; ++f) {
+            uint8_t *m = static_cast<uint8_t *>(e->pipe_main[s].p) + mbytes * f;
+            uint8_t *a = static_cast<uint8_t *>(e->pipe_add[s].p) + abytes * f;
+            HIP_TRY(e, hipMemcpy2DAsync(m, mpitch, mains[f0 + f].data, mains[f0 + f].stride, (size_t)W * mch,
+                                        H, hipMemcpyHostToDevice, e->copy_in));
+            HIP_TRY(e, hipMemcpy2DAsync(a, apitch, adds[f0 + f].data, adds[f0 + f].stride, (size_t)Wa * 3, Ha,
+                                        hipMemcpyHostToDevice, e->copy_in));
+            dm[f] = stepth_image{m, W, H, mch, STEPTH_MEM_DEVICE, mpitch};
+            da[f] = stepth_image{a, Wa, Ha, 3, STEPTH_MEM_DEVICE, apitch};
+            dd[f] = stepth_image{static_cast<uint8_t *>(e->pipe_out[s].p) + obytes * f, W, H, 1,
+                                 STEPTH_MEM_DEVICE, opitch};
+        }
+        HIP_TRY(e, hipEventRecord(e->ev_in[s], e->copy_in));
+        HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_in[s], 0));
+        TRY(stepth_depth_from_additional_batch(e, nf, dm.data(), da.data(), &dp, dd.data(), d_max + f0));
+        HIP_TRY(e, hipEventRecord(e->ev_compute[s], e->stream));
+        if (k >= 1)
+            TRY(download(k - 1));
+    }
+    TRY(download(n_chunks - 1));
+    std::vector<uint32_t> mx(n_frames);
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    HIP_TRY(e, hipMemcpyAsync(mx.data(), d_max, (size_t)n_frames * 4, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->copy_out));
+    bool any_zero = false;
+    for (uint32_t f = 0; f < n_frames; ++f) {
+        if (max_out)
+            max_out[f] = mx[f];
+        any_zero |= mx[f] == 0;
+    }
+    if (any_zero && !(p.flags & STEPTH_FLAG_RAW_ONLY))
         return fail(e, STEPTH_ERR_MAX_ZERO, "a frame's distances are all 0; its output is all zero");
     return STEPTH_OK;
 }

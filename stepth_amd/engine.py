@@ -73,6 +73,21 @@ GROUP_DTYPE = np.dtype([("x", "<u4"), ("y", "<u4"), ("w", "<u4"), ("h", "<u4"),
                         ("value", "u1", (3,)), ("pad", "u1")])
 
 
+class _PinnedBlock:
+    """owner of one stepth_host_alloc block; numpy keeps it alive as the array's base"""
+
+    def __init__(self, lib, ptr: int, n: int):
+        self._lib, self._ptr = lib, ptr
+        self.__array_interface__ = {"shape": (n,), "typestr": "|u1", "data": (ptr, False),
+                                    "version": 3}
+
+    def __del__(self):
+        try:
+            self._lib.stepth_host_free(self._ptr)
+        except Exception:
+            pass
+
+
 class PlaneList:
     """ctypes descriptions of a list of CUDA tensors (built once, reused by batch calls)."""
 
@@ -205,16 +220,21 @@ class Engine:
                                     row_pattern: Optional[Tuple[int, int, int]] = None,
                                     raw_only: bool = False, outs=None, max_out=None,
                                     asynchronous: bool = False):
-        """stepth_depth_from_additional_batch: many frames (CUDA uint8 tensors of equal shape) in
-        one set of launches, ring mode, one group per pixel.  Returns (outs, max): `outs` a list
-        of [H,W] tensors; max a list of ints, or None with asynchronous=True (then `max_out`
-        must be a CUDA int32 tensor with one element per frame, or None)."""
-        import torch
+        """stepth_depth_from_additional_batch: many frames of equal shape in one set of launches,
+        ring mode, one group per pixel.  Frames are CUDA uint8 tensors, or numpy arrays (host
+        memory: uploaded, computed and downloaded in overlapping chunks; page-locked arrays
+        from host_array() copy fastest).  Returns (outs, max): `outs` a list of [H,W] tensors
+        / arrays; max a list of ints, or None with asynchronous=True (then `max_out` must be a
+        CUDA int32 tensor with one element per frame, or None)."""
         n = len(mains)
         if n == 0 or len(additionals) != n:
             raise ValueError("mains and additionals must be equally long, non-empty lists")
         if outs is None:
-            outs = [torch.zeros(m.shape[:2], dtype=torch.uint8, device=m.device) for m in mains]
+            if _is_tensor(mains[0]):
+                import torch
+                outs = [torch.zeros(m.shape[:2], dtype=torch.uint8, device=m.device) for m in mains]
+            else:
+                outs = [np.zeros(m.shape[:2], np.uint8) for m in mains]
         mi = (L.Image * n)()
         ai = (L.Image * n)()
         di = (L.Image * n)()
@@ -245,6 +265,13 @@ class Engine:
                                                           C.cast(mx, C.c_void_p))
         self._check(st)
         return outs, [int(v) for v in mx]
+
+    def host_array(self, shape) -> np.ndarray:
+        """uint8 numpy array in page-locked memory (stepth_host_alloc), freed with the array."""
+        n = int(np.prod(shape))
+        ptr = C.c_void_p()
+        self._check(self._lib.stepth_host_alloc(C.byref(ptr), max(n, 1)))
+        return np.asarray(_PinnedBlock(self._lib, ptr.value, n)).reshape(shape)
 
     def normalise_rows(self, rows, max_value, asynchronous: bool = False, first_row: int = 0,
                        row_pattern: Optional[Tuple[int, int, int]] = None):

@@ -630,3 +630,47 @@ def test_randomised_small_cases(engine, oracle):
                 maxes.append(mx)
             np.testing.assert_array_equal(out, ref["raw"], err_msg=str((case, w, h, prec, ms, tile, parts)))
             assert max(maxes) == ref["max"]
+
+
+def test_host_batch_pipeline_matches_oracle(engine, oracle):
+    """stepth_depth_from_additional_batch on host memory (pageable and page-locked): chunks are
+    uploaded / computed / downloaded on overlapping streams; every frame bit-exact."""
+    from stepth_amd import synth
+    pairs = [synth.stereo_pair(200 + 0 * i, 120, 24, seed=100 + i)[:2] for i in range(19)]
+    mains = [np.ascontiguousarray(l) for l, _ in pairs]
+    adds = [np.ascontiguousarray(r) for _, r in pairs]
+    want = [oracle.depth_from_additional(m, a, [30, 30, 30], 40, (1, 1)) for m, a in zip(mains, adds)]
+    outs, mx = engine.depth_from_additional_batch(mains, adds, [30, 30, 30], max_steps=40)
+    for f in range(len(mains)):
+        assert mx[f] == want[f]["max"] and np.array_equal(outs[f], want[f]["depth"]), f
+    # page-locked inputs/outputs, RGBA mains with padded rows, strided outputs
+    pm = [engine.host_array((120, 208, 4))[:, :200] for _ in mains]
+    pa = [engine.host_array((120, 200, 3)) for _ in mains]
+    po = [engine.host_array((120, 256))[:, 16:216] for _ in mains]
+    for f in range(len(mains)):
+        pm[f][..., :3] = mains[f]
+        pm[f][..., 3] = 255
+        pa[f][...] = adds[f]
+        po[f][...] = 99
+    outs, mx = engine.depth_from_additional_batch(pm, pa, [30, 30, 30], max_steps=40, outs=po)
+    for f in range(len(mains)):
+        assert mx[f] == want[f]["max"] and np.array_equal(po[f], want[f]["depth"]), f
+    # raw-only strips through the same pipeline
+    outs, mx = engine.depth_from_additional_batch(mains[:3], adds[:3], [30, 30, 30], max_steps=40,
+                                                  rows=(30, 91), raw_only=True)
+    for f in range(3):
+        raw = oracle.match_groups(oracle.uniform_groups(mains[f], 1, 1), adds[f], 40,
+                                  [30, 30, 30])["raw"].reshape(120, 200)
+        assert np.array_equal(outs[f][30:91], raw[30:91]) and mx[f] == int(raw[30:91].max())
+    # mixing host and device memory is refused
+    import torch
+    with pytest.raises(Exception):
+        engine.depth_from_additional_batch([mains[0], torch.from_numpy(mains[1]).cuda()], adds[:2],
+                                           [30, 30, 30], outs=[np.zeros((120, 200), np.uint8)] * 2)
+
+
+def test_host_batch_flat_frame_reports_max_zero(engine):
+    from stepth_amd import MaxZeroError
+    flat = np.full((40, 60, 3), 90, np.uint8)
+    with pytest.raises(MaxZeroError):
+        engine.depth_from_additional_batch([flat, flat], [flat, flat], [36] * 3)
