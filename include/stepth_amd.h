@@ -281,6 +281,19 @@ int stepth_select_foreground_batch(stepth_engine *engine, uint32_t n_frames,
                                    stepth_zone *zones_out, int *statuses, uint32_t flags);
 
 /*
+ * depth_split in two halves, for a depth map whose rows are sharded over several GPUs: every
+ * rank takes the 256-bin histogram of its rows (the only pass over pixels, :171-183), the
+ * ranks sum their counts (one all_reduce of 1 KB), and every rank derives the same zones from
+ * the summed counts.  `counts` = 256 uint32 in host or device memory (`counts_memory`).
+ * stepth_depth_split(depth) == stepth_zones_from_histogram(stepth_depth_histogram(depth)).
+ */
+int stepth_depth_histogram(stepth_engine *engine, const stepth_image *depth, uint32_t *counts,
+                           uint32_t counts_memory, uint32_t flags);
+int stepth_zones_from_histogram(stepth_engine *engine, const uint32_t *counts,
+                                uint32_t counts_memory, uint32_t zones, stepth_zone *out,
+                                uint32_t capacity, uint32_t *n_out);
+
+/*
  * MaskImage::apply_mask, src/mask_image.rs:205-213: RGBA pixels whose mask byte is 0 become
  * [0;4], in place.  rgba [H][W][4], mask [H][W] u8 of the same size.
  */

@@ -101,6 +101,9 @@ SYMBOLS = {
     "stepth_invert_depth": (C.c_int, [C.c_void_p, _P(Image), C.c_uint32]),
     "stepth_depth_split": (C.c_int, [C.c_void_p, _P(Image), C.c_uint32, _P(Zone), C.c_uint32,
                                      _P(C.c_uint32)]),
+    "stepth_depth_histogram": (C.c_int, [C.c_void_p, _P(Image), C.c_void_p, C.c_uint32, C.c_uint32]),
+    "stepth_zones_from_histogram": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
+                                              _P(Zone), C.c_uint32, _P(C.c_uint32)]),
     "stepth_slice": (C.c_int, [C.c_void_p, _P(Image), _P(Zone), _P(Image), C.c_uint32]),
     "stepth_select_foreground": (C.c_int, [C.c_void_p, _P(Image), _P(Image), _P(Zone)]),
     "stepth_select_foreground_batch": (C.c_int, [C.c_void_p, C.c_uint32, _P(Image), _P(Image),

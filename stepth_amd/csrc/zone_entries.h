@@ -48,9 +48,9 @@ static int check_plane_batch(stepth_engine *e, uint32_t n, const stepth_image *i
     return STEPTH_OK;
 }
 
-// histogram + split of up to kMaxBatch device planes -> e->zone_tables[0..nf)
-static int split_device(stepth_engine *e, uint32_t nf, const uint8_t *const *planes, size_t stride,
-                        uint32_t w, uint32_t h, uint32_t zones)
+// histograms of up to kMaxBatch device planes -> e->zone_counts[0..nf)[256]
+static int histogram_device(stepth_engine *e, uint32_t nf, const uint8_t *const *planes, size_t stride,
+                            uint32_t w, uint32_t h)
 {
     TRY(reserve(e, e->zone_counts, (size_t)kMaxBatch * 256 * sizeof(uint32_t)));
     TRY(reserve(e, e->zone_tables, (size_t)kMaxBatch * sizeof(ZoneTable)));
@@ -66,6 +66,15 @@ static int split_device(stepth_engine *e, uint32_t nf, const uint8_t *const *pla
     const dim3 hgrid((uint32_t)std::min<uint64_t>((segs + 256 * kHistUnroll - 1) / (256 * kHistUnroll), per_frame), nf);
     hipLaunchKernelGGL(depth_histogram_kernel, hgrid, dim3(256), 0, e->stream, a,
                        static_cast<uint32_t *>(e->zone_counts.p));
+    HIP_TRY(e, hipGetLastError());
+    return STEPTH_OK;
+}
+
+// histogram + split of up to kMaxBatch device planes -> e->zone_tables[0..nf)
+static int split_device(stepth_engine *e, uint32_t nf, const uint8_t *const *planes, size_t stride,
+                        uint32_t w, uint32_t h, uint32_t zones)
+{
+    TRY(histogram_device(e, nf, planes, stride, w, h));
     hipLaunchKernelGGL(depth_split_kernel, dim3(nf), dim3(256), 0, e->stream,
                        static_cast<const uint32_t *>(e->zone_counts.p), zones,
                        static_cast<ZoneTable *>(e->zone_tables.p));
@@ -157,6 +166,22 @@ static void zone_from_table(const ZoneTable &t, uint32_t i, stepth_zone &z)
     z.to = t.hi[i];
 }
 
+static int zones_to_host(stepth_engine *e, uint32_t zones, stepth_zone *out, uint32_t capacity,
+                         uint32_t *n_out)
+{
+    ZoneTable t;
+    HIP_TRY(e, hipMemcpyAsync(&t, e->zone_tables.p, sizeof t, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    if (t.status != 0)
+        return fail(e, t.status, "depth_split(%u): %s", zones, stepth_status_string(t.status));
+    if (t.n > capacity)
+        return fail(e, STEPTH_ERR_BAD_ARG, "depth_split found %u zones, capacity is %u", t.n, capacity);
+    for (uint32_t i = 0; i < t.n; ++i)
+        zone_from_table(t, i, out[i]);
+    *n_out = t.n;
+    return STEPTH_OK;
+}
+
 int stepth_depth_split(stepth_engine *e, const stepth_image *depth, uint32_t zones, stepth_zone *out,
                        uint32_t capacity, uint32_t *n_out)
 {
@@ -178,17 +203,62 @@ int stepth_depth_split(stepth_engine *e, const stepth_image *depth, uint32_t zon
     size_t ss = 0;
     TRY(to_device(e, *depth, e->gauss_io, d_src, ss));
     TRY(split_device(e, 1, &d_src, ss, depth->width, depth->height, zones));
-    ZoneTable t;
-    HIP_TRY(e, hipMemcpyAsync(&t, e->zone_tables.p, sizeof t, hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(e, hipStreamSynchronize(e->stream));
-    if (t.status != 0)
-        return fail(e, t.status, "depth_split(%u): %s", zones, stepth_status_string(t.status));
-    if (t.n > capacity)
-        return fail(e, STEPTH_ERR_BAD_ARG, "depth_split found %u zones, capacity is %u", t.n, capacity);
-    for (uint32_t i = 0; i < t.n; ++i)
-        zone_from_table(t, i, out[i]);
-    *n_out = t.n;
+    return zones_to_host(e, zones, out, capacity, n_out);
+}
+
+int stepth_depth_histogram(stepth_engine *e, const stepth_image *depth, uint32_t *counts,
+                           uint32_t counts_memory, uint32_t flags)
+{
+    if (!e)
+        return STEPTH_ERR_BAD_ARG;
+    TRY(check_image(e, depth, "depth", 1, 1));
+    if (!counts || (counts_memory != STEPTH_MEM_HOST && counts_memory != STEPTH_MEM_DEVICE))
+        return fail(e, STEPTH_ERR_BAD_ARG, "counts: null pointer or bad memory kind");
+    const bool async = flags & STEPTH_FLAG_ASYNC;
+    if (async && (depth->memory != STEPTH_MEM_DEVICE || counts_memory != STEPTH_MEM_DEVICE))
+        return fail(e, STEPTH_ERR_BAD_ARG, "STEPTH_FLAG_ASYNC needs device memory everywhere");
+    HIP_TRY(e, hipSetDevice(e->device));
+    const uint8_t *d_src = nullptr;
+    size_t ss = 0;
+    TRY(to_device(e, *depth, e->gauss_io, d_src, ss));
+    TRY(histogram_device(e, 1, &d_src, ss, depth->width, depth->height));
+    HIP_TRY(e, hipMemcpyAsync(counts, e->zone_counts.p, 256 * sizeof(uint32_t),
+                              counts_memory == STEPTH_MEM_HOST ? hipMemcpyDeviceToHost
+                                                               : hipMemcpyDeviceToDevice,
+                              e->stream));
+    if (!async)
+        HIP_TRY(e, hipStreamSynchronize(e->stream));
     return STEPTH_OK;
+}
+
+int stepth_zones_from_histogram(stepth_engine *e, const uint32_t *counts, uint32_t counts_memory,
+                                uint32_t zones, stepth_zone *out, uint32_t capacity, uint32_t *n_out)
+{
+    if (!e)
+        return STEPTH_ERR_BAD_ARG;
+    if (!counts || !out || !n_out || capacity == 0 ||
+        (counts_memory != STEPTH_MEM_HOST && counts_memory != STEPTH_MEM_DEVICE))
+        return fail(e, STEPTH_ERR_BAD_ARG, "null pointer or bad memory kind");
+    *n_out = 0;
+    if (zones > 255u)
+        return fail(e, STEPTH_ERR_BAD_ARG, "zones is a u8 in the reference (got %u)", zones);
+    if (zones < 2u) { // src/depth_image.rs:163-165
+        out[0] = stepth_zone{0, 0, 0, 0};
+        *n_out = 1;
+        return STEPTH_OK;
+    }
+    HIP_TRY(e, hipSetDevice(e->device));
+    TRY(reserve(e, e->zone_counts, (size_t)kMaxBatch * 256 * sizeof(uint32_t)));
+    TRY(reserve(e, e->zone_tables, (size_t)kMaxBatch * sizeof(ZoneTable)));
+    HIP_TRY(e, hipMemcpyAsync(e->zone_counts.p, counts, 256 * sizeof(uint32_t),
+                              counts_memory == STEPTH_MEM_HOST ? hipMemcpyHostToDevice
+                                                               : hipMemcpyDeviceToDevice,
+                              e->stream));
+    hipLaunchKernelGGL(depth_split_kernel, dim3(1), dim3(256), 0, e->stream,
+                       static_cast<const uint32_t *>(e->zone_counts.p), zones,
+                       static_cast<ZoneTable *>(e->zone_tables.p));
+    HIP_TRY(e, hipGetLastError());
+    return zones_to_host(e, zones, out, capacity, n_out);
 }
 
 int stepth_slice(stepth_engine *e, const stepth_image *depth, const stepth_zone *range,

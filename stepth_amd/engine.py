@@ -341,6 +341,42 @@ class Engine:
         return [(z.from_ if z.has_from else None, z.to if z.has_to else None)
                 for z in out[:n.value]]
 
+    def depth_histogram(self, depth, out=None, asynchronous: bool = False):
+        """stepth_depth_histogram -> 256 counts (int32 CUDA tensor for a CUDA plane, else a
+        numpy uint32 array): the per-rank half of depth_split for row-sharded depth maps."""
+        di, _k = _describe(depth, (1,), "depth")
+        if _is_tensor(depth):
+            import torch
+            if out is None:
+                out = torch.empty(256, dtype=torch.int32, device=depth.device)
+            self._check(self._lib.stepth_depth_histogram(
+                self._h, C.byref(di), out.data_ptr(), L.MEM_DEVICE,
+                L.FLAG_ASYNC if asynchronous else 0))
+            return out
+        if out is None:
+            out = np.zeros(256, np.uint32)
+        self._check(self._lib.stepth_depth_histogram(self._h, C.byref(di), out.ctypes.data,
+                                                     L.MEM_HOST, 0))
+        return out
+
+    def zones_from_histogram(self, counts, zones: int):
+        """stepth_zones_from_histogram: depth_split's zones from (summed) 256 counts."""
+        out = (L.Zone * 256)()
+        n = C.c_uint32(0)
+        if _is_tensor(counts):
+            ptr, mem, keep = counts.data_ptr(), L.MEM_DEVICE, counts
+            if counts.numel() != 256 or counts.element_size() != 4 or not counts.is_contiguous():
+                raise ValueError("counts: 256 contiguous 32-bit words")
+        else:
+            keep = np.ascontiguousarray(counts, dtype=np.uint32)
+            if keep.size != 256:
+                raise ValueError("counts: 256 words")
+            ptr, mem = keep.ctypes.data, L.MEM_HOST
+        self._check(self._lib.stepth_zones_from_histogram(self._h, ptr, mem, int(zones), out, 256,
+                                                          C.byref(n)))
+        return [(z.from_ if z.has_from else None, z.to if z.has_to else None)
+                for z in out[:n.value]]
+
     def slice(self, depth, from_=None, to=None, out=None, asynchronous: bool = False):
         """stepth_slice -> mask [H,W] u8 (255 inside [from, to], 0 outside)."""
         di, _k1 = _describe(depth, (1,), "depth")

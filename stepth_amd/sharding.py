@@ -255,3 +255,65 @@ def sharded_depth(worker: StripWorker, frames: Sequence, height: int, width: int
         if b > a:
             depth[:, a:b] = recv[r, :, : b - a]
     return depth, max_all
+
+
+# ---- consumers of a row-sharded depth map (src/depth_image.rs:162-247) ---------------------
+class ZoneWorker:
+    """What a rank must be able to do on its rows of a depth map for select_foreground."""
+
+    def histogram(self, rows: torch.Tensor) -> torch.Tensor:
+        """256 counts (int32/int64 tensor on the collective's device) of the u8 rows."""
+        raise NotImplementedError
+
+    def zones(self, counts: torch.Tensor, n_zones: int):
+        """depth_split's zones [(lo, hi), ...] from the summed counts (same on every rank)."""
+        raise NotImplementedError
+
+    def slice(self, rows: torch.Tensor, lo: int, hi: int) -> torch.Tensor:
+        """mask rows: 255 where lo <= depth <= hi else 0"""
+        raise NotImplementedError
+
+
+class EngineZoneWorker(ZoneWorker):
+    """The three steps on the HIP engine (CUDA uint8 row tensors)."""
+
+    def __init__(self, engine):
+        self.engine = engine
+
+    def histogram(self, rows):
+        return self.engine.depth_histogram(rows, asynchronous=True)
+
+    def zones(self, counts, n_zones):
+        return self.engine.zones_from_histogram(counts, n_zones)
+
+    def slice(self, rows, lo, hi):
+        return self.engine.slice(rows, lo, hi, asynchronous=True)
+
+
+def sharded_select_foreground(worker: ZoneWorker, rows: torch.Tensor,
+                              group: Optional[dist.ProcessGroup] = None,
+                              sync: Optional[Callable[[], None]] = None):
+    """DepthImage::select_foreground (src/depth_image.rs:221-224) on a depth map whose rows are
+    sharded over the ranks of `group`; `rows` = this rank's [r, W] u8 rows (may be empty).
+
+    depth_split's only pass over pixels is a histogram, so the one exchange is an
+    all_reduce(SUM) of 256 counts; every rank then derives the same zones and slices its own
+    rows.  Returns (mask rows [r, W], (from, to)); gather the mask rows like the depth rows.
+    Inputs on which the reference panics raise the engine's SplitError on every rank."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if rows.numel():
+        counts = worker.histogram(rows)
+    else:
+        counts = torch.zeros(256, dtype=torch.int32, device=rows.device)
+    if world > 1:
+        if sync:
+            sync()
+        if dist.get_backend(group) == "gloo" and counts.is_cuda:
+            host = counts.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            counts = host.to(counts.device)
+        else:
+            dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
+    lo, hi = worker.zones(counts, 2)[0]
+    mask = worker.slice(rows, lo, hi) if rows.numel() else torch.empty_like(rows)
+    return mask, (lo, hi)

@@ -242,3 +242,36 @@ def _properties_at_8k(engine):
     # the histogram behind the split counts every pixel once: zone sizes add up
     torch_hist = torch.bincount(d.flatten().int(), minlength=256)
     assert int(torch_hist.sum()) == d.numel()
+
+
+def test_histogram_halves_compose_to_depth_split(engine, oracle):
+    """stepth_depth_histogram + stepth_zones_from_histogram (the row-sharded form): strips of a
+    depth map dealt to 8 'ranks', counts summed, zones == depth_split of the whole map."""
+    import torch
+    from stepth_amd.sharding import EngineZoneWorker, sharded_select_foreground, strip_bounds
+    for name, d in _depth_maps().items():
+        if d.shape[0] < 8:
+            continue
+        whole = engine.depth_histogram(d)
+        assert np.array_equal(whole, np.bincount(d.ravel(), minlength=256)), name
+        t = torch.from_numpy(d).cuda()
+        total = torch.zeros(256, dtype=torch.int32, device="cuda")
+        for r0, r1 in strip_bounds(d.shape[0], 8):
+            if r1 > r0:
+                total += engine.depth_histogram(t[r0:r1])
+        assert np.array_equal(total.cpu().numpy(), np.bincount(d.ravel(), minlength=256)), name
+        for zones in (1, 2, 3, 7):
+            ref = oracle.depth_split(d, zones)
+            if ref["status"] == 0:
+                assert engine.zones_from_histogram(total, zones) == ref["zones"], (name, zones)
+                assert engine.zones_from_histogram(whole, zones) == ref["zones"], (name, zones)
+        # world-size-1 run of the sharded helper (the collective is skipped)
+        ref = oracle.select_foreground(d)
+        if ref["status"] == 0:
+            engine.use_torch_stream()
+            try:
+                mask, zone = sharded_select_foreground(EngineZoneWorker(engine), t)
+                torch.cuda.synchronize()
+            finally:
+                engine.reset_stream()
+            assert tuple(zone) == ref["zone"] and np.array_equal(mask.cpu().numpy(), ref["mask"]), name

@@ -122,7 +122,10 @@ def _strip(r):
 
 
 def _split_by_histogram(d, zones):
-    hist = np.bincount(d.ravel(), minlength=256)
+    return _zones_from_counts(np.bincount(d.ravel(), minlength=256), zones)
+
+
+def _zones_from_counts(hist, zones):
     vals = np.nonzero(hist)[0]
     mn, mx = int(vals[0]), int(vals[-1])
     q = (mx - mn) // (zones - 1)

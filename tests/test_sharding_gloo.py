@@ -115,3 +115,67 @@ def test_single_process_path_without_init():
     depth, mx = sharded_depth(wk, [(l, r)], 40, 50)
     ref = O.depth_from_additional(l, r, [36] * 3, 64)
     np.testing.assert_array_equal(depth[0].numpy(), ref["depth"])
+
+
+# ---- select_foreground on a row-sharded depth map: all_reduce(SUM) of 256 counts ---------
+class NumpyZoneWorker:
+    """test double for EngineZoneWorker: numpy histogram / histogram k-means / threshold.
+    The k-means is the histogram formulation the GPU uses (tests/test_oracle_zones.py checks it
+    against the oracle's per-item loop); the end result is compared with the oracle."""
+
+    def histogram(self, rows):
+        return torch.from_numpy(np.bincount(rows.numpy().ravel(), minlength=256).astype(np.int64))
+
+    def zones(self, counts, n_zones):
+        from test_oracle_zones import _zones_from_counts
+        status, zones = _zones_from_counts(counts.numpy(), n_zones)
+        assert status == 0
+        return zones
+
+    def slice(self, rows, lo, hi):
+        return torch.where((rows >= lo) & (rows <= hi), 255, 0).to(torch.uint8)
+
+
+def _zone_rank(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from stepth_amd.sharding import sharded_select_foreground, strip_bounds
+        depth = _zone_depth_map()
+        r0, r1 = strip_bounds(depth.shape[0], world)[rank]
+        mask, zone = sharded_select_foreground(NumpyZoneWorker(), torch.from_numpy(depth[r0:r1].copy()))
+        q.put((rank, r0, r1, mask.numpy(), zone))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def _zone_depth_map():
+    rng = np.random.default_rng(21)
+    yy, xx = np.mgrid[0:5, 0:83]  # 5 rows over 3 ranks: one rank gets a single row
+    d = np.where(xx < 40, 20 + rng.integers(0, 30, (5, 83)), 200 + rng.integers(0, 40, (5, 83)))
+    d[0, :] = 3  # the global minimum lives on rank 0 only
+    return d.astype(np.uint8)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_select_foreground_equals_single_process(world):
+    from oracle import oracle as O
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_zone_rank, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    depth = _zone_depth_map()
+    ref = O.select_foreground(depth)
+    assert ref["status"] == 0
+    for rank, r0, r1, mask, zone in results:
+        assert tuple(zone) == ref["zone"]
+        np.testing.assert_array_equal(mask, ref["mask"][r0:r1])
