@@ -816,7 +816,18 @@ __global__ __launch_bounds__(256) STEPTH_SEARCH_ATTR void ring_search_kernel(Sea
                             n_probe += 64ull;
                             ++n_super;
                         }
-                        probe_blocks(ballot(cand), block_info(bi, bj), dmin);
+                        // nearest blocks first, in shells of 8 rings from the superblock's
+                        // nearest cell: a hit in an early shell prunes the later ones (lane
+                        // order inside a superblock says nothing about distance)
+                        const uint32_t info = block_info(bi, bj), shell = (dmin - (pick >> 8)) >> 3;
+                        unsigned long long pm = ballot(cand);
+                        for (uint32_t sh = 0; pm; ++sh) {
+                            const unsigned long long now = pm & ballot(shell <= sh);
+                            if (now) {
+                                probe_blocks(now, info, dmin);
+                                pm &= ~now & ballot(dmin < glimit);
+                            }
+                        }
                     }
                 }
             }
