@@ -651,10 +651,15 @@ __global__ __launch_bounds__(256) STEPTH_SEARCH_ATTR void ring_search_kernel(Sea
                                                               : 4u;
                 return ((uint32_t)bi & 0x3fffu) | (((uint32_t)bj & 0x3fffu) << 14) | (type << 28);
             };
+            // byte offset of block (bx,by) of this frame in T, with the block's type in bits 0..2
+            auto block_off = [&](int bx, int by, uint32_t info) {
+                return ((tf + ((uint32_t)by * a.bw + (uint32_t)bx) * 64u) << 2) | (info >> 28);
+            };
             // cell (row-major index in the block) read by this lane for a block of `type`
             auto cell_of = [&](uint32_t type) {
-                const uint32_t base = (type == 2u || type == 3u) ? lane_t : lane;
-                return base ^ (type == 1u ? 56u : type == 3u ? 7u : 0u);
+                const uint32_t base = (type & 2u) ? lane_t : lane; // 2, 3: columns
+                // 1: rows bottom-up (^56), 3: columns right-to-left (^7), else forwards
+                return base ^ (uint32_t)((0x07003800ull >> (8u * type)) & 0xffu);
             };
             // all lanes hold cell `cell` of block (sbi,sbj) (type, nearest ring d): test it for
             // every member the block can still help; keys only on a hit
@@ -688,23 +693,28 @@ __global__ __launch_bounds__(256) STEPTH_SEARCH_ATTR void ring_search_kernel(Sea
             };
             // One step of cell probes per surviving block (two in flight): 64 lanes read its
             // 64 cells (256 contiguous bytes).  `info,dmin` are per lane (lane = block).
-            auto probe_blocks = [&](unsigned long long pm, uint32_t info, uint32_t dmin) {
+            // `boff` = byte offset of the lane's block in T (a multiple of 256) | its type.
+            auto probe_blocks = [&](unsigned long long pm, uint32_t info, uint32_t dmin,
+                                    uint32_t boff) {
                 while (pm) {
                     const int b0 = __ffsll(pm) - 1;
                     pm &= pm - 1;
                     const bool two = pm != 0;
                     const int b1 = two ? __ffsll(pm) - 1 : b0;
                     pm &= pm - 1; // no-op when pm == 0
+                    const uint32_t o0 = bcast(boff, b0), o1 = bcast(boff, b1);
+                    const uint32_t t0 = o0 & 7u, t1 = o1 & 7u;
+                    const uint32_t d0 = bcast(dmin, b0), d1 = bcast(dmin, b1);
+                    const uint32_t cell0 = cell_of(t0), cell1 = cell_of(t1);
+                    const char *tb = reinterpret_cast<const char *>(a.T);
+                    const uint32_t c0 = *reinterpret_cast<const uint32_t *>(
+                        tb + (size_t)(o0 & ~255u) + (cell0 << 2));
+                    const uint32_t c1 = *reinterpret_cast<const uint32_t *>(
+                        tb + (size_t)(o1 & ~255u) + (cell1 << 2));
+                    // block coordinates are only needed for the keys of a hit
                     const uint32_t n0 = bcast(info, b0), n1 = bcast(info, b1);
                     const int i0 = (int)(n0 << 18) >> 18, j0 = (int)(n0 << 4) >> 18;
                     const int i1 = (int)(n1 << 18) >> 18, j1 = (int)(n1 << 4) >> 18;
-                    const uint32_t t0 = n0 >> 28, t1 = n1 >> 28;
-                    const uint32_t d0 = bcast(dmin, b0), d1 = bcast(dmin, b1);
-                    const uint32_t blk0 = (uint32_t)(cby + j0) * a.bw + (uint32_t)(cbx + i0);
-                    const uint32_t blk1 = (uint32_t)(cby + j1) * a.bw + (uint32_t)(cbx + i1);
-                    const uint32_t cell0 = cell_of(t0), cell1 = cell_of(t1);
-                    const uint32_t c0 = a.T[tf + blk0 * 64u + cell0];
-                    const uint32_t c1 = a.T[tf + blk1 * 64u + cell1];
                     bool changed = resolve(i0, j0, t0, d0, cell0, c0);
                     if (two)
                         changed |= resolve(i1, j1, t1, d1, cell1, c1);
@@ -737,7 +747,8 @@ __global__ __launch_bounds__(256) STEPTH_SEARCH_ATTR void ring_search_kernel(Sea
                         n_probe += 64ull;
                         ++n_near;
                     }
-                    probe_blocks(ballot(cand), block_info(bi, bj), dmin);
+                    const uint32_t info = block_info(bi, bj);
+                    probe_blocks(ballot(cand), info, dmin, block_off(bx, by, info));
                     // block-rings 0..m_done are complete: every cell of rings <= 8 m_done has
                     // been seen or excluded
                     if (best[0] != kNoKey && (best[0] >> ring_shift) <= 8u * a.spiral_done[k])
@@ -755,7 +766,8 @@ __global__ __launch_bounds__(256) STEPTH_SEARCH_ATTR void ring_search_kernel(Sea
                         n_probe += 64ull;
                         ++n_near;
                     }
-                    probe_blocks(ballot(cand), block_info(nbi, nbj), dmin);
+                    const uint32_t info = block_info(nbi, nbj);
+                    probe_blocks(ballot(cand), info, dmin, block_off(bx, by, info));
                 }
                 // a member whose best ring is <= 24 is settled; the others need the far phase
 #pragma unroll
@@ -819,12 +831,15 @@ __global__ __launch_bounds__(256) STEPTH_SEARCH_ATTR void ring_search_kernel(Sea
                         // nearest blocks first, in shells of 8 rings from the superblock's
                         // nearest cell: a hit in an early shell prunes the later ones (lane
                         // order inside a superblock says nothing about distance)
-                        const uint32_t info = block_info(bi, bj), shell = (dmin - (pick >> 8)) >> 3;
                         unsigned long long pm = ballot(cand);
+                        if (!pm)
+                            continue;
+                        const uint32_t info = block_info(bi, bj), shell = (dmin - (pick >> 8)) >> 3;
+                        const uint32_t boff = block_off(bx, by, info);
                         for (uint32_t sh = 0; pm; ++sh) {
                             const unsigned long long now = pm & ballot(shell <= sh);
                             if (now) {
-                                probe_blocks(now, info, dmin);
+                                probe_blocks(now, info, dmin, boff);
                                 pm &= ~now & ballot(dmin < glimit);
                             }
                         }
