@@ -160,6 +160,28 @@ int stepth_depth_from_additional(stepth_engine *engine, const stepth_image *main
                                  uint32_t *max_out);
 
 /*
+ * Adaptive pixel groups for `groups` above: the engine's stand-in for
+ * disage::open::rgb_discrete(img, MeanBrightnessHasher, BrightnessChecker{precision},
+ * (min_splits, max_splits)), src/depth_image.rs:101-110.  disage's source is absent from the
+ * reference tree, so the rule is this engine's own and its parity with disage is unpinned:
+ * a rectangle at depth d is a group if it is a single pixel, or d >= max_splits, or
+ * d >= min_splits and max - min < precision[c] on every channel; otherwise it is cut across
+ * its longer side into floor and ceiling halves.  value = per-channel floor(mean).
+ *   min_splits / max_splits   the reference passes 16 and ceil(log2(W*H)) (:101-103);
+ *                             max_splits = 0 means that formula
+ *   groups, capacity          receive the groups (any order), host or device memory
+ *                             (`groups_memory`); W*H entries always suffice.  groups = NULL
+ *                             only counts.
+ *   n_out                     number of groups
+ * Pass the result (device memory avoids the round trip) as `groups` to
+ * stepth_depth_from_additional.
+ */
+int stepth_adaptive_groups(stepth_engine *engine, const stepth_image *main,
+                           const uint8_t precision[3], uint32_t min_splits, uint32_t max_splits,
+                           stepth_group *groups, size_t capacity, uint32_t groups_memory,
+                           size_t *n_out);
+
+/*
  * The same path for a batch of frames in ONE set of kernel launches (the per-frame maxima stay
  * separate: each frame is normalised by its own max, src/depth_image.rs:124-129).  A single
  * small frame or row strip cannot fill the GPU -- the cost of a query varies by two orders of

@@ -131,6 +131,8 @@ struct DepthOptions {
     uint32_t max_steps = 255;         // the literal at :119
     uint32_t tile_w = 1, tile_h = 1;  // uniform groups when `groups` is empty
     std::vector<stepth_group> groups; // stand-in for disage::open::rgb_discrete's output
+    bool adaptive = false;            // groups from stepth_adaptive_groups with the reference's
+                                      // (16, ceil(log2(W*H))) splits (:101-103); own design
     bool gaussian_tail = true;        // the same-size Gaussian resample at :133-134
 };
 
@@ -254,9 +256,20 @@ class DepthImage {
         p.tile_h = opt.tile_h;
         p.flags = opt.gaussian_tail ? STEPTH_FLAG_GAUSSIAN_TAIL : 0u;
         uint32_t max = 0;
+        std::vector<stepth_group> adaptive;
+        if (opt.adaptive && opt.groups.empty()) {
+            adaptive.resize((size_t)width() * height());
+            size_t n = 0;
+            const int grc = stepth_adaptive_groups(engine, &mi, precision, 16, 0, adaptive.data(),
+                                                   adaptive.size(), STEPTH_MEM_HOST, &n);
+            if (grc != STEPTH_OK)
+                return Result::Err(stepth_last_error(engine));
+            adaptive.resize(n);
+        }
+        const std::vector<stepth_group> &gl = adaptive.empty() ? opt.groups : adaptive;
         const int rc = stepth_depth_from_additional(
-            engine, &mi, &ai, &p, opt.groups.empty() ? nullptr : opt.groups.data(),
-            opt.groups.size(), STEPTH_MEM_HOST, &di, &max);
+            engine, &mi, &ai, &p, gl.empty() ? nullptr : gl.data(), gl.size(), STEPTH_MEM_HOST,
+            &di, &max);
         if (rc == STEPTH_ERR_MAX_ZERO) {
             depth = std::move(out);
             return Result::Err(stepth_status_string(rc));

@@ -65,6 +65,9 @@ def lib(path: Optional[str] = None):
     L.oracle_uniform_groups.restype = C.c_size_t
     L.oracle_uniform_groups.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_size_t,
                                         C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+    L.oracle_adaptive_groups.restype = C.c_size_t
+    L.oracle_adaptive_groups.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_size_t,
+                                         C.c_uint32, u8p, C.c_uint32, C.c_uint32, C.c_void_p]
     L.oracle_match_groups.restype = C.c_int
     L.oracle_match_groups.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint32, C.c_uint32,
                                       C.c_size_t, C.c_uint32, u8p, C.c_int, C.c_void_p,
@@ -146,6 +149,22 @@ def uniform_groups(main: np.ndarray, tile_w: int, tile_h: int) -> np.ndarray:
     lib().oracle_uniform_groups(main.ctypes.data, w, h, main.strides[0], ch, tile_w, tile_h,
                                 groups.ctypes.data)
     return groups
+
+
+def adaptive_groups(main: np.ndarray, precision, min_splits: int = 16,
+                    max_splits: int = 0) -> np.ndarray:
+    """Adaptive stand-in for disage::open::rgb_discrete (own design, parity unpinned):
+    GROUP_DTYPE array in depth-first order; max_splits = 0 -> ceil(log2(w*h)) like
+    src/depth_image.rs:101-103."""
+    main = _img(main, (3, 4))
+    h, w, ch = main.shape
+    p = _u8x3(precision)
+    n = lib().oracle_adaptive_groups(main.ctypes.data, w, h, main.strides[0], ch, p, min_splits,
+                                     max_splits, None)
+    g = np.zeros(n, GROUP_DTYPE)
+    lib().oracle_adaptive_groups(main.ctypes.data, w, h, main.strides[0], ch, p, min_splits,
+                                 max_splits, g.ctypes.data)
+    return g
 
 
 def match_groups(groups: np.ndarray, add: np.ndarray, max_steps: int, precision,

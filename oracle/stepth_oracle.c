@@ -655,3 +655,77 @@ void oracle_apply_mask(uint8_t *rgba, const uint8_t *mask, size_t n)
         if (mask[i] == 0)
             memset(rgba + 4 * i, 0, 4);
 }
+
+/* ---- adaptive grouping stand-in (own design; disage's source is absent) ----------------- */
+
+typedef struct {
+    const uint8_t *px;
+    uint32_t channels;
+    size_t stride;
+    uint8_t prec[3];
+    uint32_t min_splits, max_splits;
+    oracle_group *out;
+    size_t n;
+} adaptive_ctx;
+
+static void adaptive_node(adaptive_ctx *c, uint32_t x, uint32_t y, uint32_t w, uint32_t h,
+                          uint32_t depth)
+{
+    int leaf = (uint64_t)w * h == 1 || depth >= c->max_splits;
+    uint64_t sum[3] = {0, 0, 0};
+    if (leaf || depth >= c->min_splits) { /* statistics of the rectangle */
+        uint8_t mn[3] = {255, 255, 255}, mx[3] = {0, 0, 0};
+        for (uint32_t yy = y; yy < y + h; ++yy)
+            for (uint32_t xx = x; xx < x + w; ++xx) {
+                const uint8_t *p = c->px + (size_t)yy * c->stride + (size_t)xx * c->channels;
+                for (int k = 0; k < 3; ++k) {
+                    sum[k] += p[k];
+                    if (p[k] < mn[k])
+                        mn[k] = p[k];
+                    if (p[k] > mx[k])
+                        mx[k] = p[k];
+                }
+            }
+        if (!leaf) {
+            leaf = 1;
+            for (int k = 0; k < 3; ++k)
+                if (!((int)mx[k] - (int)mn[k] < (int)c->prec[k]))
+                    leaf = 0;
+        }
+    }
+    if (leaf) {
+        if (c->out) {
+            oracle_group *g = &c->out[c->n];
+            g->x = x;
+            g->y = y;
+            g->w = w;
+            g->h = h;
+            for (int k = 0; k < 3; ++k)
+                g->value[k] = (uint8_t)(sum[k] / ((uint64_t)w * h));
+            g->pad = 0;
+        }
+        c->n++;
+        return;
+    }
+    if (w >= h) {
+        adaptive_node(c, x, y, w / 2, h, depth + 1);
+        adaptive_node(c, x + w / 2, y, w - w / 2, h, depth + 1);
+    } else {
+        adaptive_node(c, x, y, w, h / 2, depth + 1);
+        adaptive_node(c, x, y + h / 2, w, h - h / 2, depth + 1);
+    }
+}
+
+size_t oracle_adaptive_groups(const uint8_t *main_px, uint32_t w, uint32_t h, size_t stride,
+                              uint32_t channels, const uint8_t precision[3],
+                              uint32_t min_splits, uint32_t max_splits, oracle_group *groups)
+{
+    if (w == 0 || h == 0)
+        return 0;
+    if (max_splits == 0) /* (w*h as f32).log2().ceil(), src/depth_image.rs:101-103 */
+        max_splits = (uint32_t)ceilf(log2f((float)((uint64_t)w * h)));
+    adaptive_ctx c = {main_px, channels, stride, {precision[0], precision[1], precision[2]},
+                      min_splits, max_splits, groups, 0};
+    adaptive_node(&c, 0, 0, w, h, 0);
+    return c.n;
+}

@@ -70,6 +70,25 @@ size_t oracle_uniform_groups(const uint8_t *main_px, uint32_t w, uint32_t h, siz
                              uint32_t channels, uint32_t tile_w, uint32_t tile_h,
                              oracle_group *groups);
 
+/* Adaptive stand-in for disage::open::rgb_discrete(img, MeanBrightnessHasher,
+ * BrightnessChecker{precision}, (min_splits, max_splits)) (src/depth_image.rs:101-110).
+ * disage's source is absent from the reference tree, so this is the ENGINE'S OWN DESIGN and
+ * its parity with disage is UNPINNED; it keeps what the call site fixes: rectangular groups
+ * {position, size, value} that tile the image, at least min_splits levels of binary splitting
+ * (>= 2^16 groups on images of >= 2^16 pixels), at most max_splits levels (down to single
+ * pixels when max_splits = ceil(log2(w*h)), :103), the value a mean colour, uniformity
+ * judged with `precision`:
+ *   a rectangle at depth d is a leaf if it is a single pixel, or d >= max_splits, or
+ *   d >= min_splits and for every channel max - min < precision[c];
+ *   otherwise it is cut across its longer side (width >= height: into widths w/2 and w - w/2,
+ *   else heights h/2 and h - h/2), left/top child first;
+ *   value = per-channel floor(mean).
+ * Groups are written in depth-first order.  Returns the number of groups (also when
+ * groups == NULL).  max_splits = 0 means ceil(log2(w*h)) like :103. */
+size_t oracle_adaptive_groups(const uint8_t *main_px, uint32_t w, uint32_t h, size_t stride,
+                              uint32_t channels, const uint8_t precision[3],
+                              uint32_t min_splits, uint32_t max_splits, oracle_group *groups);
+
 /* PASS 1 of src/depth_image.rs:112-123 over groups [0,n): raw[i] = (d as u8), d = 0 on None.
  * Optional outputs: raw_u32 (d before the cast), pos_xy (winning cell, 2 per group), found.
  * threads: ORACLE_THREADS_*; REF8 reproduces par_chunks_mut(len/8) (depth_image.rs:111-112). */

@@ -82,6 +82,8 @@ SYMBOLS = {
     "stepth_depth_from_additional": (C.c_int, [C.c_void_p, _P(Image), _P(Image), _P(Params),
                                                C.c_void_p, C.c_size_t, C.c_uint32, _P(Image),
                                                C.c_void_p]),
+    "stepth_adaptive_groups": (C.c_int, [C.c_void_p, _P(Image), C.c_void_p, C.c_uint32, C.c_uint32,
+                                         C.c_void_p, C.c_size_t, C.c_uint32, _P(C.c_size_t)]),
     "stepth_depth_from_additional_batch": (C.c_int, [C.c_void_p, C.c_uint32, _P(Image), _P(Image),
                                                      _P(Params), _P(Image), C.c_void_p]),
     "stepth_host_alloc": (C.c_int, [_P(C.c_void_p), C.c_size_t]),

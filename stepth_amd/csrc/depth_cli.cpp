@@ -8,7 +8,7 @@
 //     let mut mask = img.select_foreground(); mask.apply_mask(); mask.save("foreground.jpg")?;
 // with binary PNM files in place of JPEG.
 //   stepth_depth_cli main.ppm additional.ppm out.pgm [precision] [--no-gaussian]
-//                    [--max-steps N] [--tile W H]
+//                    [--max-steps N] [--tile W H] [--adaptive]
 //   stepth_depth_cli --foreground main.ppm depth.pgm out.ppm [--zones N]
 //                    (--zones N prints depth_split(N) of the inverted depth map as well)
 //   stepth_depth_cli --check-errors      (error-message contract of the mirror, needs a GPU)
@@ -116,7 +116,7 @@ int main(int argc, char **argv)
         status = foreground(e, argc, argv);
     } else if (argc < 4) {
         fprintf(stderr, "usage: %s main.ppm additional.ppm out.pgm [precision] [--no-gaussian] "
-                        "[--max-steps N] [--tile W H]\n", argv[0]);
+                        "[--max-steps N] [--tile W H] [--adaptive]\n", argv[0]);
         status = 2;
     } else {
         uint8_t prec[3] = {255 / 7, 255 / 7, 255 / 7}; // Readme.md:14
@@ -124,6 +124,8 @@ int main(int argc, char **argv)
         for (int i = 4; i < argc; ++i) {
             if (!strcmp(argv[i], "--no-gaussian"))
                 opt.gaussian_tail = false;
+            else if (!strcmp(argv[i], "--adaptive"))
+                opt.adaptive = true;
             else if (!strcmp(argv[i], "--max-steps") && i + 1 < argc)
                 opt.max_steps = (uint32_t)atoi(argv[++i]);
             else if (!strcmp(argv[i], "--tile") && i + 2 < argc) {

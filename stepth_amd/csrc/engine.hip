@@ -19,6 +19,7 @@
 #include "ring_kernels.h"
 #include "sad_kernels.h"
 #include "zone_kernels.h"
+#include "group_kernels.h"
 
 using namespace stepth;
 
@@ -54,6 +55,7 @@ struct stepth_engine {
     DevBuf queries, raw, aux32, aux_pos, aux_found, pending, pending_rec, pending_key;
     DevBuf sad_left, sad_right, gauss_tmp, gauss_io;
     DevBuf zone_counts, zone_tables; // depth_split: 256 counts and one ZoneTable per frame
+    DevBuf group_out, group_list[2], group_counters; // adaptive grouping (group_entries.h)
     // host-image batches: two slots of device staging, copy streams and events (batch_host)
     DevBuf pipe_main[2], pipe_add[2], pipe_out[2], pipe_max;
     hipStream_t copy_in = nullptr, copy_out = nullptr;
@@ -489,7 +491,8 @@ void stepth_engine_destroy(stepth_engine *e)
                       &e->stage_groups, &e->queries, &e->raw, &e->aux32, &e->aux_pos,
                       &e->aux_found, &e->pending, &e->pending_rec, &e->pending_key, &e->sad_left, &e->sad_right, &e->gauss_tmp, &e->gauss_io,
                       &e->zone_counts, &e->zone_tables, &e->pipe_main[0], &e->pipe_main[1],
-                      &e->pipe_add[0], &e->pipe_add[1], &e->pipe_out[0], &e->pipe_out[1], &e->pipe_max})
+                      &e->pipe_add[0], &e->pipe_add[1], &e->pipe_out[0], &e->pipe_out[1], &e->pipe_max, &e->group_out,
+                      &e->group_list[0], &e->group_list[1], &e->group_counters})
         release(*b);
     for (hipEvent_t ev : {e->ev_in[0], e->ev_in[1], e->ev_compute[0], e->ev_compute[1], e->ev_out[0],
                           e->ev_out[1]})
@@ -1418,5 +1421,6 @@ int stepth_kernel_time_read(stepth_engine *e, double *total_ms, uint64_t *launch
 }
 
 #include "zone_entries.h"
+#include "group_entries.h"
 
 } // extern "C"

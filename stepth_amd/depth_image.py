@@ -141,7 +141,7 @@ class DepthImage:
 
     # src/depth_image.rs:91-136
     def load_depth_from_additional(self, add_image, precision: Sequence[int], *,
-                                   groups: Optional[np.ndarray] = None,
+                                   groups=None,
                                    tile: Tuple[int, int] = (1, 1), max_steps: int = 255,
                                    gaussian_tail: bool = True,
                                    engine: Optional[Engine] = None) -> None:
@@ -149,8 +149,10 @@ class DepthImage:
 
         `precision` is the reference's `[u8;3]`.  Keyword options are what the reference
         hard-codes or delegates to disage: `groups` (a GROUP_DTYPE array standing in for
-        disage::open::rgb_discrete's output, :104-110; default: uniform `tile`s, 1x1 = one
-        group per pixel) and `max_steps` (the literal 255 at :119).  `gaussian_tail` applies
+        disage::open::rgb_discrete's output, :104-110, or the string "adaptive" for the engine's
+        own adaptive stand-in with the reference's (16, ceil(log2(W*H))) splits -- parity with
+        disage unpinned; default: uniform `tile`s, 1x1 = one group per pixel, the configuration
+        the asset pin validates) and `max_steps` (the literal 255 at :119).  `gaussian_tail` applies
         the same-size Gaussian resample of :133-134 like the reference does (image 0.23.14's
         sampler restated -- parity unpinned); pass False for the bare depth map.
 
@@ -158,6 +160,10 @@ class DepthImage:
         leaves `self.depth` all zero."""
         add = _to_rgb8(add_image)
         eng = engine or default_engine()
+        if isinstance(groups, str):
+            if groups != "adaptive":
+                raise ValueError("groups: a GROUP_DTYPE array or \"adaptive\"")
+            groups = eng.adaptive_groups(self.image, precision, 16, 0)  # :101-103
         try:
             depth, _mx = eng.depth_from_additional(self.image, add, precision,
                                                    max_steps=max_steps, tile=tile,

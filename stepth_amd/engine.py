@@ -215,6 +215,27 @@ class Engine:
         self._check(st)
         return out, int(mx.value)
 
+    def adaptive_groups(self, main, precision, min_splits: int = 16, max_splits: int = 0):
+        """stepth_adaptive_groups: the stand-in for disage::open::rgb_discrete (own design,
+        parity unpinned).  numpy image -> GROUP_DTYPE array; CUDA tensor -> uint8 CUDA tensor
+        [n, 20] (pass either as `groups=` to depth_from_additional).  Order is arbitrary."""
+        mi, _k = _describe(main, (3, 4), "main")
+        prec = _u8x3(precision)
+        n = C.c_size_t(0)
+        cap = mi.width * mi.height
+        if _is_tensor(main):
+            import torch
+            buf = torch.empty((cap, 20), dtype=torch.uint8, device=main.device)
+            self._check(self._lib.stepth_adaptive_groups(self._h, C.byref(mi), prec, min_splits,
+                                                         max_splits, buf.data_ptr(), cap,
+                                                         L.MEM_DEVICE, C.byref(n)))
+            return buf[: n.value]
+        out = np.empty(cap, GROUP_DTYPE)
+        self._check(self._lib.stepth_adaptive_groups(self._h, C.byref(mi), prec, min_splits,
+                                                     max_splits, out.ctypes.data, cap,
+                                                     L.MEM_HOST, C.byref(n)))
+        return out[: n.value].copy()
+
     def depth_from_additional_batch(self, mains, additionals, precision, *, max_steps: int = 255,
                                     rows: Optional[Tuple[int, int]] = None,
                                     row_pattern: Optional[Tuple[int, int, int]] = None,

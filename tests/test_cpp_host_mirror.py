@@ -98,3 +98,19 @@ def test_cpp_mirror_readme_second_half_matches_oracle(oracle, asset, tmp_path):
     r = subprocess.run([CLI, "--foreground", str(tmp_path / "main.ppm"), str(tmp_path / "flat.pgm"),
                         str(out)], capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "step_by" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cpp_mirror_adaptive_groups_flow(oracle, asset, tmp_path):
+    """--adaptive: groups from stepth_adaptive_groups (stand-in for disage, own design) with the
+    reference's (16, ceil(log2(W*H))) splits, then the usual path; equals the oracle on the
+    oracle's statement of the same grouping rule."""
+    write_pnm(tmp_path / "main.ppm", asset["main"])
+    write_pnm(tmp_path / "additional.ppm", asset["additional"])
+    out = tmp_path / "depth.pgm"
+    r = subprocess.run([CLI, str(tmp_path / "main.ppm"), str(tmp_path / "additional.ppm"), str(out),
+                        "36", "--no-gaussian", "--adaptive"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    groups = oracle.adaptive_groups(asset["main"], [36] * 3)
+    ref = oracle.depth_from_additional(asset["main"], asset["additional"], [36] * 3, 255, groups=groups)
+    np.testing.assert_array_equal(read_pgm(out), ref["depth"])

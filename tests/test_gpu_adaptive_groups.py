@@ -1,0 +1,94 @@
+"""Adaptive pixel groups: stepth_adaptive_groups, the engine's stand-in for
+disage::open::rgb_discrete (src/depth_image.rs:101-110).  disage's source is absent from the
+reference tree, so the grouping rule is the engine's own design -- PARITY WITH DISAGE IS
+UNPINNED; these tests pin the GPU against the oracle's statement of the same rule (as sets:
+the order of the groups is arbitrary and no result depends on it) and check the properties the
+reference's call site fixes."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _sorted(g):
+    g = np.asarray(g)
+    return g[np.lexsort((g["x"], g["y"]))]
+
+
+def _as_groups(t):
+    from stepth_amd.engine import GROUP_DTYPE
+    return np.frombuffer(t.cpu().numpy().tobytes(), GROUP_DTYPE)
+
+
+def _cases():
+    from stepth_amd import synth
+    rng = np.random.default_rng(8)
+    yy, xx = np.mgrid[0:90, 0:130]
+    flat = np.full((64, 64, 3), 77, np.uint8)
+    return {
+        "synthetic_320x180": synth.stereo_pair(320, 180, 32, seed=3)[0],
+        "noise_97x61": rng.integers(0, 256, (61, 97, 3)).astype(np.uint8),
+        "ramp_130x90": np.stack([(xx * 255 // 129), (yy * 255 // 89), ((xx + yy) % 256)], -1).astype(np.uint8),
+        "flat_64x64": flat,
+        "one_row_300": rng.integers(0, 40, (1, 300, 3)).astype(np.uint8),
+        "one_col_300": rng.integers(0, 40, (300, 1, 3)).astype(np.uint8),
+        "tiny_3x2": rng.integers(0, 256, (2, 3, 3)).astype(np.uint8),
+        "single_pixel": np.array([[[1, 2, 3]]], np.uint8),
+    }
+
+
+@pytest.mark.parametrize("name", list(_cases()))
+def test_groups_match_oracle_as_sets(engine, oracle, name):
+    import torch
+    img = _cases()[name]
+    for prec, mn, mx in (([36] * 3, 16, 0), ([8, 20, 60], 4, 0), ([36] * 3, 0, 0), ([36] * 3, 6, 9),
+                         ([255] * 3, 3, 0), ([0] * 3, 2, 0), ([36] * 3, 12, 5)):
+        want = _sorted(oracle.adaptive_groups(img, prec, mn, mx))
+        got = _sorted(engine.adaptive_groups(img, prec, mn, mx))
+        assert len(got) == len(want), (name, prec, mn, mx)
+        assert (got == want).all(), (name, prec, mn, mx)
+        dev = _sorted(_as_groups(engine.adaptive_groups(torch.from_numpy(img).cuda(), prec, mn, mx)))
+        assert (dev == want).all(), (name, prec, mn, mx)
+
+
+def test_what_the_call_site_fixes(engine):
+    """src/depth_image.rs:101-110: groups tile the image, >= 2^16 of them on an image of >= 2^16
+    pixels (min_splits = 16), single pixels reachable (max_splits = ceil(log2(px)))"""
+    from stepth_amd import synth
+    img = synth.stereo_pair(640, 360, 64, seed=12)[0]
+    g = engine.adaptive_groups(img, [36] * 3)
+    cover = np.zeros(img.shape[:2], np.int32)
+    for r in g:
+        cover[r["y"]:r["y"] + r["h"], r["x"]:r["x"] + r["w"]] += 1
+    assert (cover == 1).all()
+    assert len(g) >= 1 << 16
+    # 640*360 px -> max_splits = 18; only rectangles of <= 2 pixels can sit at that depth (and
+    # be groups without being uniform), so every group of >= 3 pixels is uniform
+    big = g[(g["w"].astype(int) * g["h"]) >= 3]
+    assert len(big) > 1000
+    for r in big[:: max(1, len(big) // 500)]:
+        px = img[r["y"]:r["y"] + r["h"], r["x"]:r["x"] + r["w"]].reshape(-1, 3).astype(int)
+        assert ((px.max(0) - px.min(0)) < 36).all()           # uniform within precision
+        assert (r["value"] == px.sum(0) // len(px)).all()     # MeanBrightnessHasher stand-in
+    # precision 0 is never uniform: everything is cut down to max_splits = 18 levels, where the
+    # uneven halves leave rectangles of one or two pixels
+    g0 = engine.adaptive_groups(img, [0] * 3)
+    area = g0["w"].astype(int) * g0["h"]
+    assert area.max() <= 2 and area.sum() == img.shape[0] * img.shape[1]
+
+
+def test_reference_flow_with_adaptive_groups(engine, oracle, asset):
+    """the whole path the way the reference runs it (grouping -> match -> normalise -> paint),
+    groups staying on the device; equals the oracle on the same groups"""
+    import torch
+    main, add = asset["main"], asset["additional"]
+    tm, ta = torch.from_numpy(main).cuda(), torch.from_numpy(add).cuda()
+    groups = engine.adaptive_groups(tm, [36] * 3)
+    depth, mx = engine.depth_from_additional(tm, ta, [36] * 3, groups=groups)
+    want_groups = oracle.adaptive_groups(main, [36] * 3)
+    ref = oracle.depth_from_additional(main, add, [36] * 3, 255, groups=want_groups)
+    assert ref["status"] == 0 and mx == ref["max"]
+    assert np.array_equal(depth.cpu().numpy(), ref["depth"])
+    # and it still resembles the reference's shipped result (tolerance, like the 1x1 pin)
+    r = np.corrcoef(ref["depth"].astype(float).ravel(), asset["depth"].astype(float).ravel())[0, 1]
+    assert r > 0.9, r

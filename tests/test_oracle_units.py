@@ -221,3 +221,30 @@ def test_gaussian_same_size_known_answers(oracle):
     row = np.arange(0, 250, 10, dtype=np.uint8)[None, :]
     out = oracle.gaussian_same_size(row)
     assert out.shape == row.shape and abs(int(out[0, 12]) - 120) <= 1
+
+
+def test_adaptive_groups_rule_by_hand(oracle):
+    """Stand-in for disage::open::rgb_discrete (own design, parity unpinned): a 4x2 image,
+    left half flat, right half two different columns."""
+    img = np.zeros((2, 4, 3), np.uint8)
+    img[:, :2] = 10
+    img[:, 2] = 100
+    img[:, 3] = 200
+    # no forced splits, precision 5: root 4x2 not uniform -> cut the longer side (width) into
+    # 2x2 | 2x2; left uniform -> one group; right -> 1x2 | 1x2, each uniform
+    g = oracle.adaptive_groups(img, [5, 5, 5], 0, 0)
+    assert [(r["x"], r["y"], r["w"], r["h"], tuple(r["value"])) for r in g] == [
+        (0, 0, 2, 2, (10, 10, 10)), (2, 0, 1, 2, (100, 100, 100)), (3, 0, 1, 2, (200, 200, 200))]
+    # forced depth 2: the flat half is cut anyway (2x2 -> 1x2 | 1x2; width >= height cuts width)
+    g = oracle.adaptive_groups(img, [5, 5, 5], 2, 0)
+    assert sorted((r["x"], r["y"], r["w"], r["h"]) for r in g) == [(0, 0, 1, 2), (1, 0, 1, 2),
+                                                                   (2, 0, 1, 2), (3, 0, 1, 2)]
+    # max_splits caps the depth even when not uniform: depth 1 -> two 2x2 groups, value = floor mean
+    g = oracle.adaptive_groups(img, [5, 5, 5], 0, 1)
+    assert [(r["x"], r["w"], tuple(r["value"])) for r in g] == [(0, 2, (10, 10, 10)), (2, 2, (150, 150, 150))]
+    # precision 0 is never uniform: single pixels (max_splits = ceil(log2(8)) = 3)
+    assert len(oracle.adaptive_groups(img, [0, 0, 0], 0, 0)) == 8
+    # strict '<' like the matcher: a range equal to the precision is not uniform
+    two = np.array([[[10, 10, 10], [15, 10, 10]]], np.uint8)
+    assert len(oracle.adaptive_groups(two, [5, 5, 5], 0, 0)) == 2
+    assert len(oracle.adaptive_groups(two, [6, 5, 5], 0, 0)) == 1
