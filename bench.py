@@ -116,6 +116,8 @@ def main():
                     help="N > 1, ring mode: deal rows in interleaved blocks of this many rows "
                          "(0 = contiguous strips, a few % faster on the bench frames; blocks of 16 "
                          "balance the data-dependent work whatever the image content)")
+    ap.add_argument("--no-balance", action="store_true",
+                    help="N > 1: keep equal row strips instead of work-weighted ones")
     ap.add_argument("--backend", default="nccl",
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
                          "the multi-rank path with several ranks on one GPU)")
@@ -143,7 +145,7 @@ def main():
             dist.init_process_group(args.backend)
 
     from stepth_amd import MODE_RING_FIRST_HIT, MODE_SAD_WINDOW, Engine
-    from stepth_amd.sharding import EngineStripWorker, sharded_depth, strip_bounds
+    from stepth_amd.sharding import EngineStripWorker, StripBalancer, sharded_depth, strip_bounds
 
     W, H = args.width, args.height
     n_frames = args.fpg * world
@@ -159,9 +161,15 @@ def main():
     else:
         worker = EngineStripWorker(eng, prec, mode=MODE_SAD_WINDOW, d_max=args.d_max, win=args.win)
 
+    # N > 1, contiguous strips: the cut points follow the ranks' measured times from step to
+    # step (the cost of a row is data dependent); the warm-up steps let them settle
+    balancer = StripBalancer(H, world, align=2) if world > 1 and not args.interleave and \
+        not args.no_balance else None
+
     def step():
         return sharded_depth(worker, frames, H, W, dst=0 if world > 1 else None,
-                             interleave=args.interleave if args.mode == "ring" else 0)
+                             interleave=args.interleave if args.mode == "ring" else 0,
+                             balancer=balancer)
 
     def fence():
         torch.cuda.synchronize()
@@ -189,7 +197,7 @@ def main():
     # probes/pixel of this rank's strips (data-dependent work), outside the timed region
     probes_pp = None
     if args.mode == "ring":
-        r0, r1 = strip_bounds(H, world)[rank]
+        r0, r1 = (balancer.bounds if balancer is not None else strip_bounds(H, world))[rank]
         pat = None
         if args.interleave and world > 1:
             r0, r1, pat = 0, H, (args.interleave, world, rank)
@@ -206,10 +214,10 @@ def main():
     if rank == 0:
         px_step = n_frames * W * H
         value = px_step * args.steps / dt / 1e6
-        strip_rows = strip_bounds(H, world)[0]
-        # ring mode: one launch carries this rank's rows of up to 32 frames of the step (batched
+        strip_rows = balancer.bounds[0] if balancer is not None else strip_bounds(H, world)[0]
+        # ring mode: one launch carries this rank's rows of up to 64 frames of the step (batched
         # entry point); SAD mode: one launch per frame
-        frames_per_launch = min(n_frames, 32) if args.mode == "ring" else 1
+        frames_per_launch = min(n_frames, 64) if args.mode == "ring" else 1
         px_launch = (strip_rows[1] - strip_rows[0]) * W * frames_per_launch
         k_avg_ms = kms / max(klaunches, 1)
         achieved = ALGO_BYTES_PER_PIXEL * px_launch / (k_avg_ms * 1e-3) / 1e9 if klaunches else 0.0
@@ -242,7 +250,8 @@ def main():
                 "frames_per_step": n_frames, "width": W, "height": H, "d_max": args.d_max,
                 "mode": args.mode,
                 "parallelism": ((f"interleaved {args.interleave}-row strips" if args.interleave and args.mode == "ring"
-                                 else "contiguous row strips")
+                                 else "contiguous row strips, cut points following measured per-rank times"
+                                 if balancer is not None else "contiguous row strips")
                                 + f" x{world} + all_reduce(max) + gather of rows to rank 0 (RCCL)"
                                 if world > 1 else "single GPU"),
             },

@@ -37,12 +37,12 @@ struct DevBuf {
 
 } // namespace
 
-// words: [0..31] max per frame of a batch (a single call uses [0]), [32] host max staged for
-// normalise_rows, [33] pending count, then from word 64 on the kParts run counters of
+// words: [0..63] max per frame of a batch (a single call uses [0]), [64] host max staged for
+// normalise_rows, [65] pending count, then from word 128 on the kParts run counters of
 // ring_search_kernel
-constexpr uint32_t kWordHostMax = 32, kWordPending = 33, kWordCounters = 64;
+constexpr uint32_t kWordHostMax = 64, kWordPending = 65, kWordCounters = 128;
 constexpr size_t kWordsBytes = (kWordCounters + kParts * kPartStride) * 4;
-static_assert(kMaxBatch <= 32, "per-frame max words");
+static_assert(kMaxBatch <= (int)kWordHostMax, "per-frame max words");
 
 struct stepth_engine {
     int device = 0;

@@ -23,7 +23,7 @@ namespace stepth {
 //
 // with bw = ceil(Wa/8), bh = ceil(Ha/8).  One wave packs one block.
 // ---------------------------------------------------------------------------------------
-constexpr int kMaxBatch = 32; // frames one set of launches can carry (blockIdx.y / record bits)
+constexpr int kMaxBatch = 64; // frames one set of launches can carry (blockIdx.y / record bits)
 constexpr int kBlk = 8;       // block side
 constexpr int kBlkShift = 3;
 

@@ -35,6 +35,84 @@ def strip_bounds(height: int, world: int, tile_h: int = 1) -> List[Tuple[int, in
     return out
 
 
+class StripBalancer:
+    """Work-weighted contiguous row strips from measured per-rank times.
+
+    The cost of a row is data dependent (one contiguous 1/8 strip of the bench frame holds
+    27 % of its work), so equal strips leave most ranks waiting for the slowest.  Frames of a
+    stream resemble their predecessors: every step each rank times its own share, the times
+    travel with the all_reduce of the maxima (no extra collective), and all ranks derive the
+    same new cut points -- equal shares of the work under a piecewise-constant cost per row.
+    Results do not depend on where the cuts are."""
+
+    def __init__(self, height: int, world: int, align: int = 2, min_rows: int = 8,
+                 damping: float = 0.7):
+        self.height, self.world, self.align = height, world, max(1, align)
+        self.min_rows, self.damping = min_rows, damping
+        self.bounds = strip_bounds(height, world, self.align)
+        self.last_ms: Optional[float] = None  # this rank's time of the previous step
+        self._events = None
+        self._started_with = None  # bounds in force when the running measurement started
+        self.timed_bounds = None   # bounds the last read time belongs to
+
+    # -- timing of this rank's share (GPU events on the current stream, or the wall clock) --
+    def start(self, on_gpu: bool):
+        self._started_with = list(self.bounds)
+        if on_gpu:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            self._events = (a, b)
+        else:
+            import time
+            self._events = time.perf_counter()
+
+    def stop(self):
+        if isinstance(self._events, tuple):
+            self._events[1].record()
+        elif self._events is not None:
+            import time
+            self.last_ms = (time.perf_counter() - self._events) * 1e3
+            self._events = None
+
+    def previous_us(self) -> int:
+        """time of the previous step's share in microseconds (0 = none yet); call before the
+        next start()"""
+        self.timed_bounds = self._started_with
+        if isinstance(self._events, tuple):
+            a, b = self._events
+            b.synchronize()
+            self.last_ms = a.elapsed_time(b)
+            self._events = None
+        return 0 if self.last_ms is None else max(1, int(self.last_ms * 1e3))
+
+    def update(self, times_us: Sequence[int]) -> None:
+        """new cut points from every rank's time of the previous step (measured with
+        `timed_bounds`); every rank calls this with the same numbers"""
+        tb = self.timed_bounds
+        if tb is None or len(times_us) != self.world or any(t <= 0 for t in times_us):
+            return
+        dens = [t / max(b - a, 1) for (a, b), t in zip(tb, times_us)]  # cost per row
+        total = float(sum(times_us))
+        cuts, acc, r = [0], 0.0, 0
+        for k in range(1, self.world):
+            want = total * k / self.world
+            while r < self.world - 1 and acc + times_us[r] < want:
+                acc += times_us[r]
+                r += 1
+            a = tb[r][0]
+            y = a + (want - acc) / max(dens[r], 1e-9)
+            old = self.bounds[k][0]
+            y = old + self.damping * (y - old)
+            cuts.append(int(round(y / self.align)) * self.align)
+        cuts.append(self.height)
+        for k in range(1, self.world):  # keep every strip at least min_rows high
+            cuts[k] = max(cuts[k], cuts[k - 1] + self.min_rows)
+        for k in range(self.world - 1, 0, -1):
+            cuts[k] = min(cuts[k], cuts[k + 1] - self.min_rows)
+        if all(cuts[k] < cuts[k + 1] for k in range(self.world)):
+            self.bounds = [(cuts[k], cuts[k + 1]) for k in range(self.world)]
+
+
 class StripWorker:
     """What a rank must be able to do for one frame."""
 
@@ -133,7 +211,9 @@ def sharded_depth(worker: StripWorker, frames: Sequence, height: int, width: int
                   device: Optional[torch.device] = None,
                   sync: Optional[Callable[[], None]] = None,
                   dst: Optional[int] = None,
-                  interleave: int = 0) -> Tuple[Optional[torch.Tensor], torch.Tensor]:
+                  interleave: int = 0,
+                  balancer: Optional[StripBalancer] = None
+                  ) -> Tuple[Optional[torch.Tensor], torch.Tensor]:
     """Depth maps of `frames`, every frame row-strip sharded over the ranks of `group`.
 
     Returns (depth u8 [F, H, W], max int32 [F]).  Collectives per call (not per frame): one
@@ -144,11 +224,13 @@ def sharded_depth(worker: StripWorker, frames: Sequence, height: int, width: int
     `interleave` = B > 0 deals the rows in blocks of B (even, a multiple of tile_h): rank r owns
     blocks r, r+world, ... of every frame -- the work per row is data dependent and very
     uneven (one contiguous 1/8 strip of the bench frame holds 27 % of its work), interleaved
-    blocks give every rank the same mix."""
+    blocks give every rank the same mix.  `balancer` (contiguous strips only) moves the cut
+    points between steps according to the ranks' measured times instead."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     n = len(frames)
     pattern = None
+    use_balancer = False
     if interleave and world > 1:
         pattern = (interleave, world, rank)
         owned = _owned_rows(height, interleave, world)
@@ -156,7 +238,9 @@ def sharded_depth(worker: StripWorker, frames: Sequence, height: int, width: int
         r0, r1 = 0, height
         rows_max = max(len(o) for o in owned)
     else:
-        bounds = strip_bounds(height, world, tile_h)
+        use_balancer = balancer is not None and world > 1 and balancer.world == world and \
+            balancer.height == height
+        bounds = balancer.bounds if use_balancer else strip_bounds(height, world, tile_h)
         r0, r1 = bounds[rank]
         rows_max = max(b - a for a, b in bounds)
 
@@ -164,6 +248,10 @@ def sharded_depth(worker: StripWorker, frames: Sequence, height: int, width: int
         hasattr(frames[0][0], "is_cuda") and frames[0][0].is_cuda
     strips, maxes = [], []
     max_buf = None
+    prev_us = 0
+    if use_balancer:
+        prev_us = balancer.previous_us()  # the previous step's share, measured with ITS bounds
+        balancer.start(n > 0 and hasattr(frames[0][0], "is_cuda") and frames[0][0].is_cuda)
     if batched:
         strips, max_buf = worker.match_batch(frames, (r0, r1), pattern)
         maxes = [max_buf]
@@ -179,6 +267,8 @@ def sharded_depth(worker: StripWorker, frames: Sequence, height: int, width: int
             raw, mx = worker.match_strip(f, (r0, r1), **kw)
         strips.append(raw)
         maxes.append(mx)
+    if use_balancer:
+        balancer.stop()
     if device is None:
         device = maxes[0].device
     if batched:
@@ -190,6 +280,13 @@ def sharded_depth(worker: StripWorker, frames: Sequence, height: int, width: int
         max_all = torch.cat([m.reshape(1) for m in maxes]).to(torch.int32)
     # gloo (CPU rehearsals of the N > 1 path) cannot gather device tensors: stage through host
     via_host = world > 1 and dist.get_backend(group) == "gloo" and max_all.is_cuda
+    if use_balancer:
+        # the ranks' times of the previous step ride along: slot n + r belongs to rank r, the
+        # others leave it 0, so the MAX reduction hands every rank all of them
+        ext = torch.zeros(n + world, dtype=torch.int32, device=max_all.device)
+        ext[:n] = max_all
+        ext[n + rank] = prev_us
+        max_all = ext
     if world > 1:
         if sync:
             sync()
@@ -199,6 +296,9 @@ def sharded_depth(worker: StripWorker, frames: Sequence, height: int, width: int
             max_all = m_host.to(device)
         else:
             dist.all_reduce(max_all, op=dist.ReduceOp.MAX, group=group)  # src/depth_image.rs:124
+    if use_balancer:  # cut points for the NEXT step; this step finishes on `bounds`
+        times_us, max_all = [int(t) for t in max_all[n:].tolist()], max_all[:n]
+        balancer.update(times_us)
     if batched:  # src/depth_image.rs:125-129
         worker.normalise_batch(strips, max_all, first_row=r0, pattern=pattern)
     for i, raw in enumerate([] if batched else strips):

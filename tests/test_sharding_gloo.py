@@ -179,3 +179,80 @@ def test_sharded_select_foreground_equals_single_process(world):
     for rank, r0, r1, mask, zone in results:
         assert tuple(zone) == ref["zone"]
         np.testing.assert_array_equal(mask, ref["mask"][r0:r1])
+
+
+# ---- work-weighted strips: cut points move between steps, results must not -----------------
+def test_strip_balancer_moves_cuts_towards_equal_time():
+    from stepth_amd.sharding import StripBalancer
+    b = StripBalancer(1080, 4, align=2, damping=1.0)
+    assert b.bounds == [(0, 270), (270, 540), (540, 810), (810, 1080)]
+    b.timed_bounds = list(b.bounds)
+    b.update([100, 100, 300, 100])          # rank 2's rows cost three times as much
+    # total 600 -> 150 each: cut 1 at 270 + 50/100*270 = 405, cut 2 inside strip 2 at
+    # 540 + (300 - 200)/300 * 270 = 630, cut 3 at 540 + 250/300 * 270 = 765
+    cuts = [r0 for r0, _r1 in b.bounds[1:]]
+    assert all(abs(c - w) <= 2 for c, w in zip(cuts, (405, 630, 765))) and all(c % 2 == 0 for c in cuts)
+    assert b.bounds[0][0] == 0 and b.bounds[-1][1] == 1080
+    assert all(b.bounds[k][1] == b.bounds[k + 1][0] for k in range(3))
+    before = list(b.bounds)
+    b.update([0, 1, 1, 1])                   # a missing time: leave the cuts alone
+    assert b.bounds == before
+    b.timed_bounds = list(b.bounds)
+    b.update([1, 1, 1, 10 ** 6])             # never squeeze a strip below min_rows
+    assert all(r1 - r0 >= 8 for r0, r1 in b.bounds) and b.bounds[-1][1] == 1080
+
+
+def _balanced_rank(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import time
+        from stepth_amd import synth
+        from stepth_amd.sharding import StripBalancer, sharded_depth
+        l, r, _ = synth.stereo_pair(97, 61, 16, seed=5)
+
+        class Slow(OracleStripWorker):  # rank 1 pretends to be three times slower
+            def match_strip(self, frame, rows, max_out=None, pattern=None):
+                out = super().match_strip(frame, rows, max_out, pattern)
+                time.sleep(0.03 * (3 if rank == 1 else 1) * max(rows[1] - rows[0], 1) / 30)
+                return out
+
+        wk = Slow([36] * 3, 64, (1, 1))
+        bal = StripBalancer(61, world, align=1, min_rows=4)
+        history, depths = [], []
+        for _step in range(5):
+            history.append(list(bal.bounds))
+            depth, mx = sharded_depth(wk, [(l, r)], 61, 97, balancer=bal)
+            depths.append(depth.numpy().copy())
+        q.put((rank, history, depths, mx.numpy()))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_balanced_strips_give_the_same_depth_and_shift_work():
+    from oracle import oracle as O
+    from stepth_amd import synth
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_balanced_rank, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    l, r, _ = synth.stereo_pair(97, 61, 16, seed=5)
+    ref = O.depth_from_additional(l, r, [36] * 3, 64)
+    hist0 = results[0][1]
+    for rank, history, depths, mx in results:
+        assert history == hist0                      # every rank derived the same cut points
+        for d in depths:
+            np.testing.assert_array_equal(d[0], ref["depth"])
+        assert int(mx[0]) == ref["max"]
+    first, last = hist0[0], hist0[-1]
+    assert first != last                             # the cuts moved ...
+    assert (last[1][1] - last[1][0]) < (first[1][1] - first[1][0])  # ... away from the slow rank
