@@ -16,6 +16,7 @@ lives in half-coordinate space ((y+1)/2 - 254 ... ) and is not a thin halo (SURV
 """
 from __future__ import annotations
 
+import collections
 from typing import Callable, List, Optional, Sequence, Tuple
 
 import torch
@@ -50,45 +51,57 @@ class StripBalancer:
         self.height, self.world, self.align = height, world, max(1, align)
         self.min_rows, self.damping = min_rows, damping
         self.bounds = strip_bounds(height, world, self.align)
-        self.last_ms: Optional[float] = None  # this rank's time of the previous step
-        self._events = None
-        self._started_with = None  # bounds in force when the running measurement started
-        self.timed_bounds = None   # bounds the last read time belongs to
+        self.last_ms: Optional[float] = None  # this rank's most recent finished measurement
+        self.timed_bounds = None   # ... and the strips it was taken with
+        self._open = None          # measurement being taken
+        self._timings = collections.deque()  # GPU measurements not read yet
+        self.pending = None        # (all-reduced times tensor, their bounds) of the last call
 
     # -- timing of this rank's share (GPU events on the current stream, or the wall clock) --
     def start(self, on_gpu: bool):
-        self._started_with = list(self.bounds)
         if on_gpu:
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            self._events = (a, b)
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+            self._open = (ev, list(self.bounds))
         else:
             import time
-            self._events = time.perf_counter()
+            self._open = (time.perf_counter(), list(self.bounds))
 
     def stop(self):
-        if isinstance(self._events, tuple):
-            self._events[1].record()
-        elif self._events is not None:
+        if self._open is None:
+            return
+        mark, bounds = self._open
+        self._open = None
+        if isinstance(mark, tuple):
+            mark[1].record()
+            self._timings.append((mark, bounds))  # read later, once the GPU has got there
+        else:
             import time
-            self.last_ms = (time.perf_counter() - self._events) * 1e3
-            self._events = None
+            self.last_ms, self.timed_bounds = (time.perf_counter() - mark) * 1e3, bounds
 
     def previous_us(self) -> int:
-        """time of the previous step's share in microseconds (0 = none yet); call before the
-        next start()"""
-        self.timed_bounds = self._started_with
-        if isinstance(self._events, tuple):
-            a, b = self._events
+        """the previous step's measurement in microseconds (0 = none yet) and, in
+        `timed_bounds`, the strips it was taken with.  Every rank reads the SAME step's
+        measurement (the cut points must come out identical everywhere), so a GPU measurement
+        still in flight is waited for -- it ends before that step's normalise and gather, which
+        are what keeps the GPU busy meanwhile."""
+        if self._timings:
+            (a, b), bounds = self._timings.popleft()
             b.synchronize()
-            self.last_ms = a.elapsed_time(b)
-            self._events = None
+            self.last_ms, self.timed_bounds = a.elapsed_time(b), bounds
         return 0 if self.last_ms is None else max(1, int(self.last_ms * 1e3))
 
-    def update(self, times_us: Sequence[int]) -> None:
-        """new cut points from every rank's time of the previous step (measured with
-        `timed_bounds`); every rank calls this with the same numbers"""
-        tb = self.timed_bounds
+    def apply_pending(self) -> None:
+        """new cut points from the times all-reduced during the previous call"""
+        if self.pending is not None:
+            times, tb = self.pending
+            self.pending = None
+            self.update([int(t) for t in times.tolist()], tb)
+
+    def update(self, times_us: Sequence[int], timed_bounds=None) -> None:
+        """new cut points from every rank's time of one step, measured with `timed_bounds`;
+        every rank calls this with the same numbers"""
+        tb = timed_bounds if timed_bounds is not None else self.timed_bounds
         if tb is None or len(times_us) != self.world or any(t <= 0 for t in times_us):
             return
         dens = [t / max(b - a, 1) for (a, b), t in zip(tb, times_us)]  # cost per row
@@ -240,6 +253,8 @@ def sharded_depth(worker: StripWorker, frames: Sequence, height: int, width: int
     else:
         use_balancer = balancer is not None and world > 1 and balancer.world == world and \
             balancer.height == height
+        if use_balancer:
+            balancer.apply_pending()  # times exchanged during the previous call
         bounds = balancer.bounds if use_balancer else strip_bounds(height, world, tile_h)
         r0, r1 = bounds[rank]
         rows_max = max(b - a for a, b in bounds)
@@ -296,9 +311,10 @@ def sharded_depth(worker: StripWorker, frames: Sequence, height: int, width: int
             max_all = m_host.to(device)
         else:
             dist.all_reduce(max_all, op=dist.ReduceOp.MAX, group=group)  # src/depth_image.rs:124
-    if use_balancer:  # cut points for the NEXT step; this step finishes on `bounds`
-        times_us, max_all = [int(t) for t in max_all[n:].tolist()], max_all[:n]
-        balancer.update(times_us)
+    if use_balancer:
+        # read on the next call, when the reduction has long finished: no host sync here
+        balancer.pending = (max_all[n:], balancer.timed_bounds)
+        max_all = max_all[:n]
     if batched:  # src/depth_image.rs:125-129
         worker.normalise_batch(strips, max_all, first_row=r0, pattern=pattern)
     for i, raw in enumerate([] if batched else strips):
