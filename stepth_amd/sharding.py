@@ -328,7 +328,8 @@ def sharded_depth(worker: StripWorker, frames: Sequence, height: int, width: int
             return worker.last_base[:, r0:r1], max_all
         return torch.stack([s for s in strips]), max_all
 
-    send = torch.zeros((n, rows_max, width), dtype=torch.uint8, device=device)
+    # rows beyond this rank's own are padding that nobody reads
+    send = torch.empty((n, rows_max, width), dtype=torch.uint8, device=device)
     base = getattr(worker, "last_base", None) if batched else None
     if pattern:
         mine = _owned_on(owned, rank, device)
@@ -347,12 +348,14 @@ def sharded_depth(worker: StripWorker, frames: Sequence, height: int, width: int
         sync()
     if dst is not None:
         coll_dev = torch.device("cpu") if via_host else device
-        parts = ([torch.empty((n, rows_max, width), dtype=torch.uint8, device=coll_dev)
-                  for _ in range(world)] if rank == dst else None)
-        dist.gather(send.cpu() if via_host else send, parts, dst=dst, group=group)
+        # the root receives straight into one [world, n, rows, W] buffer (views as the list)
+        recv = (torch.empty((world, n, rows_max, width), dtype=torch.uint8, device=coll_dev)
+                if rank == dst else None)
+        dist.gather(send.cpu() if via_host else send,
+                    list(recv.unbind(0)) if rank == dst else None, dst=dst, group=group)
         if rank != dst:
             return None, max_all
-        recv = torch.stack(parts).to(device)
+        recv = recv.to(device)
     else:
         recv = torch.empty((world, n, rows_max, width), dtype=torch.uint8, device=device)
         if via_host:
