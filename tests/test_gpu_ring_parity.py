@@ -674,3 +674,24 @@ def test_host_batch_flat_frame_reports_max_zero(engine):
     flat = np.full((40, 60, 3), 90, np.uint8)
     with pytest.raises(MaxZeroError):
         engine.depth_from_additional_batch([flat, flat], [flat, flat], [36] * 3)
+
+
+@pytest.mark.parametrize("w,h", [(20000, 5), (5, 20000), (65535, 1), (1, 65535)])
+def test_extreme_aspect_ratios(engine, oracle, w, h):
+    """the C-ABI admits sides up to 65535: very wide / very tall images (rings clipped on one
+    axis almost immediately, block grids of one row or one column)"""
+    rng = np.random.default_rng(w * 31 + h)
+    main = (rng.integers(0, 4, (h, w, 3)) * 60).astype(np.uint8)
+    add = np.roll(main, 7 if w > h else 0, axis=1)
+    add = np.roll(add, 7 if h > w else 0, axis=0).copy()
+    add[rng.random((h, w)) < 0.02] = 255
+    for ms in (40, 255):
+        ref = oracle.depth_from_additional(main, add, [36] * 3, ms, (1, 1))
+        d, mx = engine.depth_from_additional(main, add, [36] * 3, max_steps=ms)
+        assert mx == ref["max"] and np.array_equal(d, ref["depth"]), (w, h, ms)
+    g = oracle.adaptive_groups(main, [36] * 3)
+    got = engine.adaptive_groups(main, [36] * 3)
+    assert np.array_equal(np.sort(g, order=["y", "x"]), np.sort(got, order=["y", "x"]))
+    refg = oracle.depth_from_additional(main, add, [36] * 3, 255, groups=g)
+    dg, _ = engine.depth_from_additional(main, add, [36] * 3, groups=got)
+    assert np.array_equal(dg, refg["depth"])
