@@ -695,3 +695,37 @@ def test_extreme_aspect_ratios(engine, oracle, w, h):
     refg = oracle.depth_from_additional(main, add, [36] * 3, 255, groups=g)
     dg, _ = engine.depth_from_additional(main, add, [36] * 3, groups=got)
     assert np.array_equal(dg, refg["depth"])
+
+
+def test_two_engines_on_two_threads(oracle):
+    """different DepthImages may be processed from different threads (the crate
+    has no globals) -> the C library is re-entrant per handle: one engine per thread, calls
+    overlapping in time (ctypes releases the GIL), each result exact."""
+    import threading
+    from stepth_amd import Engine, synth
+    pairs = [synth.stereo_pair(240, 160, 32, seed=40 + i)[:2] for i in range(2)]
+    want = [oracle.depth_from_additional(l, r, [36] * 3, 255)["depth"] for l, r in pairs]
+    errors = []
+
+    def work(i):
+        try:
+            with Engine(0) as eng:
+                l, r = pairs[i]
+                for _ in range(20):
+                    d, _mx = eng.depth_from_additional(l, r, [36] * 3)
+                    if not np.array_equal(d, want[i]):
+                        errors.append(f"thread {i}: depth differs")
+                        return
+                    m, _z = eng.select_foreground(255 - d)
+                    if not np.array_equal(m, oracle.select_foreground(255 - want[i])["mask"]):
+                        errors.append(f"thread {i}: mask differs")
+                        return
+        except Exception as e:  # noqa: BLE001
+            errors.append(f"thread {i}: {e!r}")
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=120)
+    assert not errors, errors
