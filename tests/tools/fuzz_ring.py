@@ -1,6 +1,6 @@
 """one-off differential fuzz of the ring path against the oracle: larger images than the suite's
 randomised test (far phase, superblock steps, shells), many seeds"""
-import sys, time; sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
+import sys, time; sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__)))))
 import numpy as np
 from stepth_amd import Engine, MaxZeroError, synth
 from oracle import oracle as O
