@@ -124,3 +124,27 @@ def test_strip_bounds():
     assert all(a % 5 == 0 for a, _ in b) and all(x[1] == y[0] for x, y in zip(b, b[1:]))
     assert strip_bounds(3, 8)[3:] == [(3, 3)] * 5
     assert strip_bounds(7, 2, tile_h=5) == [(0, 5), (5, 7)]
+
+
+def test_header_is_plain_c_and_links_from_c(tmp_path):
+    """the boundary is a C ABI: include/stepth_amd.h must compile as C99 and a C program must
+    link against libstepth_amd.so (what a cgo / Rust `extern "C"` binding relies on)"""
+    import subprocess
+    from stepth_amd import _lib
+    hdr = os.path.join(ROOT, "include", "stepth_amd.h")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only",
+                        "-x", "c", hdr], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    src = tmp_path / "use.c"
+    src.write_text('#include "stepth_amd.h"\n#include <stdio.h>\n'
+                   'int main(void) { stepth_engine *e = 0; int rc = stepth_engine_create(-1, &e);\n'
+                   '  printf("%u %d %s\\n", stepth_abi_version(), rc, stepth_status_string(rc));\n'
+                   '  stepth_engine_destroy(e); return 0; }\n')
+    exe = tmp_path / "use_c"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    r = subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-L", libdir,
+                        "-lstepth_amd", f"-Wl,-rpath,{libdir}", "-o", str(exe)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0 and out.stdout.split()[0] == str(_lib.ABI_VERSION), out.stdout + out.stderr
