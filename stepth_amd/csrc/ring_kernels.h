@@ -784,11 +784,14 @@ __global__ __launch_bounds__(256) STEPTH_SEARCH_ATTR void ring_search_kernel(Sea
                     const int sx1 = min((int)qx + rad, (int)a.wa - 1) >> 6;
                     const int sy1 = min((int)qy + rad, (int)a.ha - 1) >> 6;
                     const int nsx = sx1 - sx0 + 1, nsy = sy1 - sy0 + 1; // <= 10 each
-                    // superblock t of the window sits at (t % 16, t / 16): 3 rounds cover 16 x 12
+                    // lanes tile the window: 8 x 8 superblocks in one round when it fits (any
+                    // window of radius <= 223), else 16 x 4 per round, 3 rounds cover 16 x 12
+                    const uint32_t gsh = (nsx <= 8 && nsy <= 8) ? 3u : 4u;
+                    const int grows = 64 >> gsh;
                     uint32_t skey[3] = {kNoKey, kNoKey, kNoKey};
 #pragma unroll
                     for (int h = 0; h < 3; ++h) {
-                        const int tx = (int)(lane & 15u), ty = (int)(lane >> 4) + 4 * h;
+                        const int tx = (int)(lane & ((1u << gsh) - 1u)), ty = (int)(lane >> gsh) + grows * h;
                         if (tx < nsx && ty < nsy) {
                             const int sx = sx0 + tx, sy = sy0 + ty;
                             const int ax = (sx << 6) - (int)qx, ay = (sy << 6) - (int)qy;
@@ -798,7 +801,7 @@ __global__ __launch_bounds__(256) STEPTH_SEARCH_ATTR void ring_search_kernel(Sea
                                 wanted(a.SB[sf + (uint32_t)sy * a.sbw + (uint32_t)sx], dS))
                                 skey[h] = (dS << 8) | (uint32_t)(ty * 16 + tx);
                         }
-                        if (4 * (h + 1) >= nsy)
+                        if (grows * (h + 1) >= nsy)
                             break;
                     }
                     if constexpr (STATS) {
