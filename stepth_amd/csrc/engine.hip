@@ -289,6 +289,9 @@ int launch_ring(stepth_engine *e, RingArgs &ra, int qmode, uint32_t n_frames = 1
     ra.spiral = (const uint32_t *)e->spiral.p;
     ra.spiral_done = ra.spiral + (size_t)e->spiral_chunks * 64;
     const size_t n_all = (size_t)ra.n * n_frames;
+    ra.id_bits = n_frames > 1 ? 26u : 32u; // callers batch only frames of <= 2^26 queries
+    if (n_frames > 1 && ra.n > (1u << 26))
+        return fail(e, STEPTH_ERR_BAD_ARG, "batch of frames with more than 2^26 queries each");
     TRY(reserve(e, e->pending, n_all * 4));
     ra.pending = (uint32_t *)e->pending.p;
     TRY(reserve(e, e->pending_rec, n_all * sizeof(Query)));
@@ -329,6 +332,7 @@ int launch_ring(stepth_engine *e, RingArgs &ra, int qmode, uint32_t n_frames = 1
     fa.key = sa.key;
     fa.count = ra.pending_count;
     fa.pos_bits = ra.pos_bits;
+    fa.id_bits = ra.id_bits;
     fa.raw = ra.raw;
     fa.raw32 = ra.raw32;
     fa.pos = ra.pos;
@@ -955,8 +959,10 @@ int stepth_depth_from_additional_batch(stepth_engine *e, uint32_t n_frames,
     // frames per set of launches: at most kMaxBatch, and few enough that all their cells can be
     // indexed with 32 bits
     const uint64_t cells = (uint64_t)((adds[0].width + 7u) / 8u) * ((adds[0].height + 7u) / 8u) * 64u;
-    const uint32_t chunk = (uint32_t)std::max<uint64_t>(
+    uint32_t chunk = (uint32_t)std::max<uint64_t>(
         1, std::min<uint64_t>(kMaxBatch, 0x3FFFFFFFull / std::max<uint64_t>(cells, 1)));
+    if ((uint64_t)W * rows > (1ull << 26)) // the pending ids keep 6 bits for the frame
+        chunk = 1;
     for (uint32_t f0 = 0; f0 < n_frames; f0 += chunk) {
         const uint32_t nf = std::min<uint32_t>(chunk, n_frames - f0);
         const uint8_t *d_adds[kMaxBatch];

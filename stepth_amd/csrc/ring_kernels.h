@@ -264,6 +264,7 @@ struct RingArgs {
     const Query *queries;
     uint32_t n;
     uint32_t max_steps;
+    uint32_t id_bits; // pending ids: query id in the low id_bits, frame above (32: one frame)
     uint8_t prec[3];
     uint8_t *raw;      // n: (d as u8), depth_image.rs:121
     uint32_t *raw32;   // optional: d
@@ -482,7 +483,9 @@ __global__ __launch_bounds__(256) void ring0_kernel(RingArgs a)
         const unsigned long long pm = __ballot(pending);
         if (pending) {
             const uint32_t at = slot + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull));
-            a.pending[at] = qid[it];
+            // the id carries the frame in its top bits (batches): ring_finish_kernel then needs
+            // 8 bytes per pending query, not the 16-byte record as well
+            a.pending[at] = a.id_bits < 32u ? qid[it] | (f << a.id_bits) : qid[it];
             a.pending_rec[at] = rec[it];
         }
         slot += (uint32_t)__popcll(pm);
@@ -877,6 +880,7 @@ struct FinishArgs {
     const uint32_t *key;
     const uint32_t *count;
     uint32_t pos_bits;
+    uint32_t id_bits; // pending ids: query id in the low id_bits, frame above (32: no frame)
     uint8_t *raw;
     uint32_t *raw32, *pos;
     uint8_t *found;
@@ -898,8 +902,9 @@ __global__ __launch_bounds__(256) void ring_finish_kernel(FinishArgs a)
         const uint32_t key = a.key[i];
         if (key == kNoKey)
             continue;
-        const Query r = a.rec[i];
-        const uint32_t frame = r.cy >> 16, q = a.pending[i];
+        const uint32_t idw = a.pending[i];
+        const uint32_t frame = a.id_bits < 32u ? idw >> a.id_bits : 0u;
+        const uint32_t q = a.id_bits < 32u ? idw & ((1u << a.id_bits) - 1u) : idw;
         int dx, dy;
         key_to_offset(key, a.pos_bits, dx, dy);
         const uint32_t d = isqrt_floor((uint32_t)(dx * dx + dy * dy));
@@ -909,6 +914,7 @@ __global__ __launch_bounds__(256) void ring_finish_kernel(FinishArgs a)
         if (a.raw32)
             a.raw32[q] = d;
         if (a.pos) {
+            const Query r = a.rec[i];
             a.pos[2 * (size_t)q] = (uint32_t)((int)r.cx + dx);
             a.pos[2 * (size_t)q + 1] = (uint32_t)((int)(r.cy & 0xffffu) + dy);
         }
