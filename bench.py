@@ -116,6 +116,8 @@ def main():
                     help="N > 1, ring mode: deal rows in interleaved blocks of this many rows "
                          "(0 = contiguous strips, a few % faster on the bench frames; blocks of 16 "
                          "balance the data-dependent work whatever the image content)")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="N > 1: finish every step's gather before the next step starts")
     ap.add_argument("--no-balance", action="store_true",
                     help="N > 1: keep equal row strips instead of work-weighted ones")
     ap.add_argument("--backend", default="nccl",
@@ -145,7 +147,8 @@ def main():
             dist.init_process_group(args.backend)
 
     from stepth_amd import MODE_RING_FIRST_HIT, MODE_SAD_WINDOW, Engine
-    from stepth_amd.sharding import EngineStripWorker, StripBalancer, sharded_depth, strip_bounds
+    from stepth_amd.sharding import (EngineStripWorker, GatherPipeline, StripBalancer, sharded_depth,
+                                     strip_bounds)
 
     W, H = args.width, args.height
     n_frames = args.fpg * world
@@ -166,10 +169,14 @@ def main():
     balancer = StripBalancer(H, world, align=2) if world > 1 and not args.interleave and \
         not args.no_balance else None
 
+    # N > 1: the gather of a step's rows to rank 0 runs behind the next step's kernels; the
+    # last step's gather is flushed inside the timed region
+    pipeline = GatherPipeline() if world > 1 and not args.interleave and not args.no_overlap else None
+
     def step():
         return sharded_depth(worker, frames, H, W, dst=0 if world > 1 else None,
                              interleave=args.interleave if args.mode == "ring" else 0,
-                             balancer=balancer)
+                             balancer=balancer, pipeline=pipeline)
 
     def fence():
         torch.cuda.synchronize()
@@ -180,11 +187,15 @@ def main():
     depth = None
     for _ in range(args.warmup):
         depth, _mx = step()
+    if pipeline is not None:
+        pipeline.flush()
     fence()
     eng.kernel_time_enable(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         depth, _mx = step()
+    if pipeline is not None:
+        depth = pipeline.flush()  # the last step's rows; part of the timed work
     fence()
     dt = time.perf_counter() - t0
     kms, klaunches = eng.kernel_time_read()
@@ -252,7 +263,8 @@ def main():
                 "parallelism": ((f"interleaved {args.interleave}-row strips" if args.interleave and args.mode == "ring"
                                  else "contiguous row strips, cut points following measured per-rank times"
                                  if balancer is not None else "contiguous row strips")
-                                + f" x{world} + all_reduce(max) + gather of rows to rank 0 (RCCL)"
+                                + f" x{world} + all_reduce(max) + gather of rows to rank 0 (RCCL"
+                                + (", overlapped with the next step's kernels)" if pipeline is not None else ")")
                                 if world > 1 else "single GPU"),
             },
             "roofline": {

@@ -126,6 +126,43 @@ class StripBalancer:
             self.bounds = [(cuts[k], cuts[k + 1]) for k in range(self.world)]
 
 
+class GatherPipeline:
+    """Lets the gather of one step's rows run behind the next step's kernels.
+
+    With `pipeline=` sharded_depth only STARTS the gather to the root (async collective) and
+    returns the depth maps of the PREVIOUS call: the root waits for and assembles them after
+    it has enqueued its own PASS 1 of the next step, so the xGMI transfers hide behind ~4 ms of
+    kernels instead of stalling every rank at the end of each step.  `flush()` hands out the
+    maps of the last call (and must be called before the results are used or the clock is
+    stopped).  Gather-to-root with contiguous strips only."""
+
+    def __init__(self):
+        self._inflight = None  # (work, recv, send, bounds, n, height, width, device)
+        self.depth = None      # depth maps of the most recent finished step (root only)
+
+    def finish_previous(self) -> None:
+        if self._inflight is None:
+            return
+        work, recv, _send, bounds, n, height, width, device = self._inflight
+        self._inflight = None
+        if work is not None:
+            work.wait()  # the current stream waits for the collective; the host does not
+        if recv is None:
+            self.depth = None
+            return
+        recv = recv.to(device)
+        depth = torch.empty((n, height, width), dtype=torch.uint8, device=device)
+        for r, (a, b) in enumerate(bounds):
+            if b > a:
+                depth[:, a:b] = recv[r, :, : b - a]
+        self.depth = depth
+
+    def flush(self):
+        """-> depth maps of the last call (None on the other ranks)"""
+        self.finish_previous()
+        return self.depth
+
+
 class StripWorker:
     """What a rank must be able to do for one frame."""
 
@@ -225,7 +262,8 @@ def sharded_depth(worker: StripWorker, frames: Sequence, height: int, width: int
                   sync: Optional[Callable[[], None]] = None,
                   dst: Optional[int] = None,
                   interleave: int = 0,
-                  balancer: Optional[StripBalancer] = None
+                  balancer: Optional[StripBalancer] = None,
+                  pipeline: Optional[GatherPipeline] = None
                   ) -> Tuple[Optional[torch.Tensor], torch.Tensor]:
     """Depth maps of `frames`, every frame row-strip sharded over the ranks of `group`.
 
@@ -238,7 +276,9 @@ def sharded_depth(worker: StripWorker, frames: Sequence, height: int, width: int
     blocks r, r+world, ... of every frame -- the work per row is data dependent and very
     uneven (one contiguous 1/8 strip of the bench frame holds 27 % of its work), interleaved
     blocks give every rank the same mix.  `balancer` (contiguous strips only) moves the cut
-    points between steps according to the ranks' measured times instead."""
+    points between steps according to the ranks' measured times instead.  `pipeline`
+    (GatherPipeline; needs `dst`, contiguous strips) overlaps the gather with the next call's
+    kernels: the depth returned is then the PREVIOUS call's (None the first time)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     n = len(frames)
@@ -284,6 +324,9 @@ def sharded_depth(worker: StripWorker, frames: Sequence, height: int, width: int
         maxes.append(mx)
     if use_balancer:
         balancer.stop()
+    use_pipeline = pipeline is not None and world > 1 and dst is not None and pattern is None
+    if use_pipeline:
+        pipeline.finish_previous()  # its transfers ran behind the kernels enqueued above
     if device is None:
         device = maxes[0].device
     if batched:
@@ -351,8 +394,13 @@ def sharded_depth(worker: StripWorker, frames: Sequence, height: int, width: int
         # the root receives straight into one [world, n, rows, W] buffer (views as the list)
         recv = (torch.empty((world, n, rows_max, width), dtype=torch.uint8, device=coll_dev)
                 if rank == dst else None)
-        dist.gather(send.cpu() if via_host else send,
-                    list(recv.unbind(0)) if rank == dst else None, dst=dst, group=group)
+        send_c = send.cpu() if via_host else send
+        if use_pipeline:
+            work = dist.gather(send_c, list(recv.unbind(0)) if rank == dst else None, dst=dst,
+                               group=group, async_op=True)
+            pipeline._inflight = (work, recv, send_c, bounds, n, height, width, device)
+            return pipeline.depth, max_all
+        dist.gather(send_c, list(recv.unbind(0)) if rank == dst else None, dst=dst, group=group)
         if rank != dst:
             return None, max_all
         recv = recv.to(device)

@@ -256,3 +256,53 @@ def test_balanced_strips_give_the_same_depth_and_shift_work():
     first, last = hist0[0], hist0[-1]
     assert first != last                             # the cuts moved ...
     assert (last[1][1] - last[1][0]) < (first[1][1] - first[1][0])  # ... away from the slow rank
+
+
+# ---- pipelined gather: results lag one call, flush() delivers the last ----------------------
+def _pipelined_rank(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from stepth_amd import synth
+        from stepth_amd.sharding import GatherPipeline, StripBalancer, sharded_depth
+        wk = OracleStripWorker([36] * 3, 64, (1, 1))
+        pipe, bal = GatherPipeline(), StripBalancer(61, world, align=1, min_rows=4)
+        got = []
+        for seed in (1, 2, 3):
+            l, r, _ = synth.stereo_pair(97, 61, 16, seed=seed)
+            depth, mx = sharded_depth(wk, [(l, r)], 61, 97, dst=0, balancer=bal, pipeline=pipe)
+            got.append((None if depth is None else depth.numpy().copy(), mx.numpy().copy()))
+        last = pipe.flush()
+        q.put((rank, got, None if last is None else last.numpy().copy()))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_pipelined_gather_lags_one_call_and_flushes():
+    from oracle import oracle as O
+    from stepth_amd import synth
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pipelined_rank, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    refs = [O.depth_from_additional(*synth.stereo_pair(97, 61, 16, seed=s)[:2], [36] * 3, 64) for s in (1, 2, 3)]
+    for rank, got, last in results:
+        for i, (depth, mx) in enumerate(got):
+            assert int(mx[0]) == refs[i]["max"]          # the maxima are this call's
+            if rank == 0 and i > 0:
+                np.testing.assert_array_equal(depth[0], refs[i - 1]["depth"])  # maps lag one call
+            else:
+                assert depth is None
+        if rank == 0:
+            np.testing.assert_array_equal(last[0], refs[2]["depth"])
+        else:
+            assert last is None
