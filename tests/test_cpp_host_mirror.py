@@ -114,3 +114,14 @@ def test_cpp_mirror_adaptive_groups_flow(oracle, asset, tmp_path):
     groups = oracle.adaptive_groups(asset["main"], [36] * 3)
     ref = oracle.depth_from_additional(asset["main"], asset["additional"], [36] * 3, 255, groups=groups)
     np.testing.assert_array_equal(read_pgm(out), ref["depth"])
+
+
+@pytest.mark.gpu
+def test_cabi_check_program():
+    """stepth_amd/csrc/cabi_check.cpp: every entry point of the C-ABI from plain C++ (host batch
+    pipeline == single calls, device-resident adaptive groups -> list mode, consumers, SAD,
+    tiles, Gaussian, page-locked memory)"""
+    exe = os.path.join(ROOT, "stepth_amd", "stepth_cabi_check")
+    assert os.path.exists(exe), "run __graft_entry__.build()"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0 and "CABI-CHECK-OK" in r.stdout, r.stdout + r.stderr
