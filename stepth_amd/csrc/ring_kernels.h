@@ -285,7 +285,7 @@ struct RingArgs {
 
 constexpr uint32_t kNoKey = 0xFFFFFFFFu;
 #ifndef STEPTH_RUN
-#define STEPTH_RUN 32
+#define STEPTH_RUN 64
 #endif
 // <= 80 SGPRs keeps 8 workgroups of 256 threads resident per CU (MI355X_MICROARCH.md,
 // "Residency"); the kernel wants ~100 without the cap
