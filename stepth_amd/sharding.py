@@ -322,11 +322,11 @@ def sharded_depth(worker: StripWorker, frames: Sequence, height: int, width: int
             raw, mx = worker.match_strip(f, (r0, r1), **kw)
         strips.append(raw)
         maxes.append(mx)
-    if use_balancer:
-        balancer.stop()
     use_pipeline = pipeline is not None and world > 1 and dst is not None and pattern is None
     if use_pipeline:
         pipeline.finish_previous()  # its transfers ran behind the kernels enqueued above
+    if use_balancer:
+        balancer.stop()  # PASS 1 plus, on the root, the assembly of the previous step's rows
     if device is None:
         device = maxes[0].device
     if batched:
