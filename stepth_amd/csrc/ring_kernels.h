@@ -543,9 +543,9 @@ __global__ __launch_bounds__(256) STEPTH_SEARCH_ATTR void ring_search_kernel(Sea
     // line: a single counter would cap the whole chip at ~88 grabs/us.  A wave starts at
     // partition wave % kParts and moves on when it is empty.
     // long runs amortise the grab, short runs balance small launches (a row strip of 1/8
-    // frame has only ~24 records per wave): aim at >= 16 runs per resident wave, runs of
+    // frame has only ~24 records per wave): aim at >= 8 runs per resident wave, runs of
     // 4..kRun records (multiples of 4: the 2x2 tiles put up to 4 records on one centre)
-    const uint32_t run = min(kRun, max(4u, (count / (8192u * 16u)) & ~3u));
+    const uint32_t run = min(kRun, max(4u, (count / (8192u * 8u)) & ~3u));
     const uint32_t n_runs = (count + run - 1u) / run;
     const uint32_t wave_id =
         (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (threadIdx.x >> 6)));
