@@ -418,7 +418,7 @@ __device__ __forceinline__ bool load_query(const RingArgs &a, uint32_t f, uint32
 // One returning atomic on a single address costs ~11 ns chip-wide (MI355X_MICROARCH.md,
 // "dequeue"), so the compaction counter is bumped once per WORKGROUP (kRing0Iters * 256
 // queries), not once per wave.
-constexpr uint32_t kRing0Iters = 4;
+constexpr uint32_t kRing0Iters = 8;
 
 template <int QMODE, bool STATS>
 __global__ __launch_bounds__(256) void ring0_kernel(RingArgs a)
