@@ -343,7 +343,7 @@ int launch_ring(stepth_engine *e, RingArgs &ra, int qmode, uint32_t n_frames = 1
     // search waves pull runs of queries from counters, so any grid works; 8 workgroups of 4
     // waves per CU is the most that can be resident
     const uint32_t search_blocks = (uint32_t)std::min<size_t>(2048u, (n_all + 63u) / 64u);
-    const uint32_t finish_blocks = (uint32_t)std::min<size_t>(512u, (n_all + 255u) / 256u);
+    const uint32_t finish_blocks = (uint32_t)std::min<size_t>(1024u, (n_all + 255u) / 256u);
     // block-rings a search can reach; the near + superblock scheme covers 33 of them
     const bool far_search =
         ((std::min(ra.max_steps, std::max(ra.wa, ra.ha)) + 6u) >> 3) > kSpiralRings;
