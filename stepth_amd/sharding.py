@@ -56,6 +56,7 @@ class StripBalancer:
         self._open = None          # measurement being taken
         self._timings = collections.deque()  # GPU measurements not read yet
         self.pending = None        # (all-reduced times tensor, their bounds) of the last call
+        self._updates = 0
 
     # -- timing of this rank's share (GPU events on the current stream, or the wall clock) --
     def start(self, on_gpu: bool):
@@ -115,7 +116,9 @@ class StripBalancer:
             a = tb[r][0]
             y = a + (want - acc) / max(dens[r], 1e-9)
             old = self.bounds[k][0]
-            y = old + self.damping * (y - old)
+            # the first correction goes all the way (equal strips are far off), later ones
+            # are damped against noise
+            y = old + (1.0 if self._updates == 0 else self.damping) * (y - old)
             cuts.append(int(round(y / self.align)) * self.align)
         cuts.append(self.height)
         for k in range(1, self.world):  # keep every strip at least min_rows high
@@ -124,6 +127,7 @@ class StripBalancer:
             cuts[k] = min(cuts[k], cuts[k + 1] - self.min_rows)
         if all(cuts[k] < cuts[k + 1] for k in range(self.world)):
             self.bounds = [(cuts[k], cuts[k + 1]) for k in range(self.world)]
+            self._updates += 1
 
 
 class GatherPipeline:
