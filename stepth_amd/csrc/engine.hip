@@ -55,7 +55,7 @@ struct stepth_engine {
     DevBuf queries, raw, aux32, aux_pos, aux_found, pending, pending_rec, pending_key;
     DevBuf sad_left, sad_right, gauss_tmp, gauss_io;
     DevBuf zone_counts, zone_tables; // depth_split: 256 counts and one ZoneTable per frame
-    DevBuf group_out, group_list[2], group_counters; // adaptive grouping (group_entries.h)
+    DevBuf group_out, group_list[3], group_counters; // adaptive grouping (group_entries.h)
     // host-image batches: two slots of device staging, copy streams and events (batch_host)
     DevBuf pipe_main[2], pipe_add[2], pipe_out[2], pipe_max;
     hipStream_t copy_in = nullptr, copy_out = nullptr;
@@ -270,7 +270,10 @@ int launch_ring(stepth_engine *e, RingArgs &ra, int qmode, uint32_t n_frames = 1
     const uint32_t slots = qmode == 0 ? ra.n_slots : ra.n;
     if (slots == 0) // a row pattern can leave a rank without rows
         return STEPTH_OK;
-    const uint32_t blocks = (slots + 256u * kRing0Iters - 1u) / (256u * kRing0Iters);
+    // few queries (a short group list, a thin strip): smaller workgroups, so that every CU gets one
+    const bool small_launch = (uint64_t)slots * n_frames < (1u << 20);
+    const uint32_t r0_iters = small_launch ? kRing0ItersSmall : kRing0Iters;
+    const uint32_t blocks = (slots + 256u * r0_iters - 1u) / (256u * r0_iters);
     TRY(ensure_spiral(e, ra.max_steps, ra.wa, ra.ha));
     {
         // 32-bit scan keys: ring | side(2) | position; sized for the farthest reachable ring
@@ -348,16 +351,19 @@ int launch_ring(stepth_engine *e, RingArgs &ra, int qmode, uint32_t n_frames = 1
     const bool far_search =
         ((std::min(ra.max_steps, std::max(ra.wa, ra.ha)) + 6u) >> 3) > kSpiralRings;
     const bool st = e->stats_enabled;
-    if (qmode == 0) {
-        if (st)
-            hipLaunchKernelGGL((ring0_kernel<0, true>), dim3(blocks, n_frames), dim3(256), 0, e->stream, ra);
-        else
-            hipLaunchKernelGGL((ring0_kernel<0, false>), dim3(blocks, n_frames), dim3(256), 0, e->stream, ra);
-    } else {
-        if (st)
-            hipLaunchKernelGGL((ring0_kernel<1, true>), dim3(blocks), dim3(256), 0, e->stream, ra);
-        else
-            hipLaunchKernelGGL((ring0_kernel<1, false>), dim3(blocks), dim3(256), 0, e->stream, ra);
+    {
+        const dim3 g0(blocks, qmode == 0 ? n_frames : 1u), b0(256);
+#define STEPTH_RING0(Q, S, I) hipLaunchKernelGGL((ring0_kernel<Q, S, I>), g0, b0, 0, e->stream, ra)
+        if (qmode == 0 && small_launch) {
+            if (st) STEPTH_RING0(0, true, kRing0ItersSmall); else STEPTH_RING0(0, false, kRing0ItersSmall);
+        } else if (qmode == 0) {
+            if (st) STEPTH_RING0(0, true, kRing0Iters); else STEPTH_RING0(0, false, kRing0Iters);
+        } else if (small_launch) {
+            if (st) STEPTH_RING0(1, true, kRing0ItersSmall); else STEPTH_RING0(1, false, kRing0ItersSmall);
+        } else {
+            if (st) STEPTH_RING0(1, true, kRing0Iters); else STEPTH_RING0(1, false, kRing0Iters);
+        }
+#undef STEPTH_RING0
     }
     {
     KernelTimer t(e); // the dominant kernel only (bench.py's roofline leg)
@@ -496,7 +502,7 @@ void stepth_engine_destroy(stepth_engine *e)
                       &e->aux_found, &e->pending, &e->pending_rec, &e->pending_key, &e->sad_left, &e->sad_right, &e->gauss_tmp, &e->gauss_io,
                       &e->zone_counts, &e->zone_tables, &e->pipe_main[0], &e->pipe_main[1],
                       &e->pipe_add[0], &e->pipe_add[1], &e->pipe_out[0], &e->pipe_out[1], &e->pipe_max, &e->group_out,
-                      &e->group_list[0], &e->group_list[1], &e->group_counters})
+                      &e->group_list[0], &e->group_list[1], &e->group_list[2], &e->group_counters})
         release(*b);
     for (hipEvent_t ev : {e->ev_in[0], e->ev_in[1], e->ev_compute[0], e->ev_compute[1], e->ev_out[0],
                           e->ev_out[1]})

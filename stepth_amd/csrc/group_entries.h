@@ -30,8 +30,8 @@ int stepth_adaptive_groups(stepth_engine *e, const stepth_image *main_im, const 
     size_t ms = 0;
     TRY(to_device(e, *main_im, e->stage_main, d_main, ms));
     TRY(reserve(e, e->group_out, (size_t)px * sizeof(GroupRec)));
-    TRY(reserve(e, e->group_list[0], (size_t)px * sizeof(GroupNode)));
-    TRY(reserve(e, e->group_list[1], (size_t)px * sizeof(GroupNode)));
+    for (int k = 0; k < 3; ++k)
+        TRY(reserve(e, e->group_list[k], (size_t)px * sizeof(GroupNode)));
     TRY(reserve(e, e->group_counters, 16));
     AdaptiveArgs a{};
     a.px = d_main;
@@ -45,19 +45,16 @@ int stepth_adaptive_groups(stepth_engine *e, const stepth_image *main_im, const 
     a.max_splits = max_splits;
     a.seed_depth = seed_depth;
     a.groups = static_cast<GroupRec *>(e->group_out.p);
-    a.list[0] = static_cast<GroupNode *>(e->group_list[0].p);
-    a.list[1] = static_cast<GroupNode *>(e->group_list[1].p);
+    for (int k = 0; k < 3; ++k)
+        a.list[k] = static_cast<GroupNode *>(e->group_list[k].p);
     a.counters = static_cast<uint32_t *>(e->group_counters.p);
     HIP_TRY(e, hipMemsetAsync(a.counters, 0, 16, e->stream));
     const uint64_t seeds = 1ull << seed_depth;
     hipLaunchKernelGGL(adaptive_seed_kernel, dim3((uint32_t)std::min<uint64_t>((seeds + 255) / 256, 4096)),
                        dim3(256), 0, e->stream, a);
     const uint32_t level_grid = (uint32_t)std::min<uint64_t>((px + 255) / 256, 2048);
-    for (uint32_t d = seed_depth + 1; d <= max_splits; ++d) {
-        // level d appends to the list level d-1 has just consumed
-        hipLaunchKernelGGL(adaptive_reset_kernel, dim3(1), dim3(1), 0, e->stream, a.counters + 1 + ((d + 1) & 1u));
+    for (uint32_t d = seed_depth + 1; d <= max_splits; ++d) // three lists rotate, see the kernel
         hipLaunchKernelGGL(adaptive_level_kernel, dim3(level_grid), dim3(256), 0, e->stream, a, d);
-    }
     HIP_TRY(e, hipGetLastError());
     uint32_t n = 0;
     HIP_TRY(e, hipMemcpyAsync(&n, a.counters, 4, hipMemcpyDeviceToHost, e->stream));

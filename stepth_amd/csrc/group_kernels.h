@@ -35,8 +35,8 @@ struct AdaptiveArgs {
     uint32_t prec[3];
     uint32_t min_splits, max_splits, seed_depth; // seed_depth = min(min_splits, max_splits)
     GroupRec *groups;                            // capacity W*H
-    GroupNode *list[2];                          // node lists of alternating levels
-    uint32_t *counters;                          // [0] groups, [1 + (level & 1)] list lengths
+    GroupNode *list[3];                          // node lists of levels d, d+1, d+2 (rotating)
+    uint32_t *counters;                          // [0] groups, [1 + level % 3] list lengths
 };
 
 // appends `v` for the lanes with `yes` to an array with length counter `count`: one atomic
@@ -157,25 +157,26 @@ __global__ __launch_bounds__(256) void adaptive_seed_kernel(AdaptiveArgs a)
                 n.h = second ? n.h - h0 : h0;
             }
         }
-        adaptive_visit(a, live, n, depth, a.list[(a.seed_depth + 1) & 1], &a.counters[1 + ((a.seed_depth + 1) & 1)]);
+        adaptive_visit(a, live, n, depth, a.list[(a.seed_depth + 1) % 3], &a.counters[1 + (a.seed_depth + 1) % 3]);
     }
 }
 
-// nodes of depth `depth` (list[depth & 1]) -> groups and nodes of depth + 1
+// nodes of depth `depth` (list[depth % 3]) -> groups and nodes of depth + 1 (list[(depth+1) % 3]).
+// The third list is the one level depth - 1 has consumed: its counter is cleared here for
+// level depth + 1 to append to (no launch in between needs it).
 __global__ __launch_bounds__(256) void adaptive_level_kernel(AdaptiveArgs a, uint32_t depth)
 {
-    const uint32_t count = a.counters[1 + (depth & 1)];
+    const uint32_t count = a.counters[1 + depth % 3];
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        a.counters[1 + (depth + 2) % 3] = 0;
     const uint32_t rounds = (count + gridDim.x * 256 - 1) / (gridDim.x * 256);
-    const GroupNode *in = a.list[depth & 1];
+    const GroupNode *in = a.list[depth % 3];
     for (uint32_t r = 0; r < rounds; ++r) {
         const uint32_t i = (r * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
         const bool live = i < count;
         const GroupNode n = live ? in[i] : GroupNode{0, 0, 1, 1};
-        adaptive_visit(a, live, n, depth, a.list[(depth + 1) & 1], &a.counters[1 + ((depth + 1) & 1)]);
+        adaptive_visit(a, live, n, depth, a.list[(depth + 1) % 3], &a.counters[1 + (depth + 1) % 3]);
     }
 }
-
-// between two levels: the list that was just consumed becomes the output list of the next level
-__global__ void adaptive_reset_kernel(uint32_t *counter) { *counter = 0; }
 
 } // namespace stepth

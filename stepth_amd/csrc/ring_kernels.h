@@ -417,23 +417,24 @@ __device__ __forceinline__ bool load_query(const RingArgs &a, uint32_t f, uint32
 
 // One returning atomic on a single address costs ~11 ns chip-wide (MI355X_MICROARCH.md,
 // "dequeue"), so the compaction counter is bumped once per WORKGROUP (kRing0Iters * 256
-// queries), not once per wave.
-constexpr uint32_t kRing0Iters = 8;
+// queries), not once per wave: 2048 queries per workgroup for big launches (ITERS = 8), 512
+// for small ones, which would otherwise leave most CUs without a workgroup (ITERS = 2).
+constexpr uint32_t kRing0Iters = 8, kRing0ItersSmall = 2;
 
-template <int QMODE, bool STATS>
+template <int QMODE, bool STATS, uint32_t ITERS>
 __global__ __launch_bounds__(256) void ring0_kernel(RingArgs a)
 {
     __shared__ uint32_t s_wave_total[4];
     __shared__ uint32_t s_base;
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const uint32_t f = blockIdx.y; // frame
-    Query rec[kRing0Iters];
-    uint32_t qid[kRing0Iters];
+    Query rec[ITERS];
+    uint32_t qid[ITERS];
     uint32_t pend_bits = 0, n_mine = 0;
     unsigned long long n_hit = 0, n_inb = 0;
 #pragma unroll
-    for (uint32_t it = 0; it < kRing0Iters; ++it) {
-        const uint32_t slot = (blockIdx.x * kRing0Iters + it) * 256u + threadIdx.x;
+    for (uint32_t it = 0; it < ITERS; ++it) {
+        const uint32_t slot = (blockIdx.x * ITERS + it) * 256u + threadIdx.x;
         uint32_t q = 0, cx = ~0u, cy = ~0u, lo = 0, hi = 0;
         const bool valid = load_query<QMODE>(a, f, slot, q, cx, cy, lo, hi);
         qid[it] = q;
@@ -478,7 +479,7 @@ __global__ __launch_bounds__(256) void ring0_kernel(RingArgs a)
     for (uint32_t w = 0; w < wv; ++w)
         slot += s_wave_total[w];
 #pragma unroll
-    for (uint32_t it = 0; it < kRing0Iters; ++it) {
+    for (uint32_t it = 0; it < ITERS; ++it) {
         const bool pending = (pend_bits >> it) & 1u;
         const unsigned long long pm = __ballot(pending);
         if (pending) {
