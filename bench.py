@@ -36,6 +36,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# The steps alternate over two HIP streams (see main); with the runtime's default of 4 hardware
+# queues the two streams sometimes end up on the same queue and serialise, with 8 they do not.
+# Must be set before the HIP runtime starts, i.e. before torch is imported.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -116,6 +121,9 @@ def main():
                     help="N > 1, ring mode: deal rows in interleaved blocks of this many rows "
                          "(0 = contiguous strips, a few % faster on the bench frames; blocks of 16 "
                          "balance the data-dependent work whatever the image content)")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="steps alternate over this many engines/HIP streams (1 = strictly one "
+                         "step after the other)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="N > 1: finish every step's gather before the next step starts")
     ap.add_argument("--no-balance", action="store_true",
@@ -155,28 +163,70 @@ def main():
     frames_np = make_frames(W, H, args.d_max, n_frames)
     frames = [(torch.from_numpy(l).to(dev), torch.from_numpy(r).to(dev)) for l, r in frames_np]
 
-    eng = Engine(local_rank)
-    eng.use_torch_stream()
+    # Steps alternate over `--streams` engines, each on its own HIP stream: while one step's
+    # search kernel drains, the next step's pack / ring-0 kernels (HBM-bound) and the previous
+    # step's finish / paint already run -- two batches in flight, like any streaming pipeline.
+    n_slots = max(1, args.streams)
+    torch.cuda.synchronize()  # the uploads above
+    engines = [Engine(local_rank) for _ in range(n_slots)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(n_slots)] if n_slots > 1 else [None]
+    for e_, s_ in zip(engines, streams):
+        if s_ is None:
+            e_.use_torch_stream()
+        else:
+            with torch.cuda.stream(s_):
+                e_.use_torch_stream()
+    eng = engines[0]
     prec = [args.precision] * 3
-    if args.mode == "ring":
-        worker = EngineStripWorker(eng, prec, max_steps=args.d_max, tile=(1, 1),
-                                   mode=MODE_RING_FIRST_HIT)
-    else:
-        worker = EngineStripWorker(eng, prec, mode=MODE_SAD_WINDOW, d_max=args.d_max, win=args.win)
+
+    def make_worker(e_):
+        if args.mode == "ring":
+            return EngineStripWorker(e_, prec, max_steps=args.d_max, tile=(1, 1), mode=MODE_RING_FIRST_HIT)
+        return EngineStripWorker(e_, prec, mode=MODE_SAD_WINDOW, d_max=args.d_max, win=args.win)
+
+    workers = [make_worker(e_) for e_ in engines]
+    worker = workers[0]
 
     # N > 1, contiguous strips: the cut points follow the ranks' measured times from step to
     # step (the cost of a row is data dependent); the warm-up steps let them settle
-    balancer = StripBalancer(H, world, align=2) if world > 1 and not args.interleave and \
-        not args.no_balance else None
+    balancer = StripBalancer(H, world, align=2, lag=n_slots) if world > 1 and not args.interleave \
+        and not args.no_balance else None
 
-    # N > 1: the gather of a step's rows to rank 0 runs behind the next step's kernels; the
-    # last step's gather is flushed inside the timed region
-    pipeline = GatherPipeline() if world > 1 and not args.interleave and not args.no_overlap else None
+    # N > 1: the gather of a step's rows to rank 0 runs behind the following kernels; the
+    # outstanding gathers are flushed inside the timed region
+    pipelines = [GatherPipeline() if world > 1 and not args.interleave and not args.no_overlap
+                 else None for _ in range(n_slots)]
+    pipeline = pipelines[0]
+    step_no = [0]
 
     def step():
-        return sharded_depth(worker, frames, H, W, dst=0 if world > 1 else None,
-                             interleave=args.interleave if args.mode == "ring" else 0,
-                             balancer=balancer, pipeline=pipeline)
+        slot = step_no[0] % n_slots
+        step_no[0] += 1
+
+        def run():
+            return sharded_depth(workers[slot], frames, H, W, dst=0 if world > 1 else None,
+                                 interleave=args.interleave if args.mode == "ring" else 0,
+                                 balancer=balancer, pipeline=pipelines[slot])
+        if streams[slot] is None:
+            return run()
+        with torch.cuda.stream(streams[slot]):
+            return run()
+
+    def flush():
+        """finishes the gathers still in flight, oldest first; -> depth maps of the last step"""
+        last = None
+        for k in range(n_slots):
+            slot = (step_no[0] + k) % n_slots  # the slot of the oldest outstanding step first
+            if pipelines[slot] is None:
+                continue
+            if streams[slot] is None:
+                d = pipelines[slot].flush()
+            else:
+                with torch.cuda.stream(streams[slot]):
+                    d = pipelines[slot].flush()
+            if slot == (step_no[0] - 1) % n_slots:
+                last = d
+        return last
 
     def fence():
         torch.cuda.synchronize()
@@ -188,18 +238,23 @@ def main():
     for _ in range(args.warmup):
         depth, _mx = step()
     if pipeline is not None:
-        pipeline.flush()
+        flush()
     fence()
-    eng.kernel_time_enable(True)
+    for e_ in engines:
+        e_.kernel_time_enable(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         depth, _mx = step()
     if pipeline is not None:
-        depth = pipeline.flush()  # the last step's rows; part of the timed work
+        depth = flush()  # the last step's rows; part of the timed work
     fence()
     dt = time.perf_counter() - t0
-    kms, klaunches = eng.kernel_time_read()
-    eng.kernel_time_enable(False)
+    kms = klaunches = 0
+    for e_ in engines:
+        k_, l_ = e_.kernel_time_read()
+        kms, klaunches = kms + k_, klaunches + l_
+        e_.kernel_time_enable(False)
+    eng.use_torch_stream()  # the extra legs below run on the default stream
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -265,7 +320,8 @@ def main():
                                  if balancer is not None else "contiguous row strips")
                                 + f" x{world} + all_reduce(max) + gather of rows to rank 0 (RCCL"
                                 + (", overlapped with the next step's kernels)" if pipeline is not None else ")")
-                                if world > 1 else "single GPU"),
+                                if world > 1 else "single GPU")
+                               + (f"; steps alternate over {n_slots} engines/HIP streams" if n_slots > 1 else ""),
             },
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
@@ -334,7 +390,8 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    eng.close()
+    for e_ in engines:
+        e_.close()
 
 
 if __name__ == "__main__":

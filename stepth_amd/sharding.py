@@ -47,7 +47,11 @@ class StripBalancer:
     Results do not depend on where the cuts are."""
 
     def __init__(self, height: int, world: int, align: int = 2, min_rows: int = 8,
-                 damping: float = 0.7):
+                 damping: float = 0.7, lag: int = 1):
+        """`lag` = calls in flight at once (steps alternating over that many streams): the
+        measurement read at call k is the one of call k - lag, so reading it never waits for
+        work that is meant to overlap with call k."""
+        self.lag = max(1, lag)
         self.height, self.world, self.align = height, world, max(1, align)
         self.min_rows, self.damping = min_rows, damping
         self.bounds = strip_bounds(height, world, self.align)
@@ -86,7 +90,7 @@ class StripBalancer:
         measurement (the cut points must come out identical everywhere), so a GPU measurement
         still in flight is waited for -- it ends before that step's normalise and gather, which
         are what keeps the GPU busy meanwhile."""
-        if self._timings:
+        if len(self._timings) >= self.lag:
             (a, b), bounds = self._timings.popleft()
             b.synchronize()
             self.last_ms, self.timed_bounds = a.elapsed_time(b), bounds
