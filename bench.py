@@ -281,9 +281,8 @@ def main():
         px_step = n_frames * W * H
         value = px_step * args.steps / dt / 1e6
         strip_rows = balancer.bounds[0] if balancer is not None else strip_bounds(H, world)[0]
-        # ring mode: one launch carries this rank's rows of up to 64 frames of the step (batched
-        # entry point); SAD mode: one launch per frame
-        frames_per_launch = min(n_frames, 64) if args.mode == "ring" else 1
+        # one launch carries this rank's rows of up to 64 frames of the step (batched entry point)
+        frames_per_launch = min(n_frames, 64)
         px_launch = (strip_rows[1] - strip_rows[0]) * W * frames_per_launch
         k_avg_ms = kms / max(klaunches, 1)
         achieved = ALGO_BYTES_PER_PIXEL * px_launch / (k_avg_ms * 1e-3) / 1e9 if klaunches else 0.0
@@ -352,8 +351,9 @@ def main():
                 "value": round(px_step / sdt / 1e6, 3), "unit": "Mpixels/s",
                 "workload": f"windowed SAD {args.win}x{args.win}, d_max={args.d_max}, same frames",
                 "kernel": "sad_search_kernel", "kernel_avg_ms": round(sms / max(sl, 1), 4),
-                "hbm_frac": round(ALGO_BYTES_PER_PIXEL * W * H / (sms / max(sl, 1) * 1e-3) / 1e9
-                                  / HBM_PEAK_GBS, 6)}
+                "frames_per_launch": min(n_frames, 64),
+                "hbm_frac": round(ALGO_BYTES_PER_PIXEL * W * H * min(n_frames, 64)
+                                  / (sms / max(sl, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)}
         if args.mode == "ring" and world == 1:
             # README's second half on the depth maps of the last step (Readme.md:18-24):
             # select_foreground = histogram + depth_split(2) + slice, three launches for all

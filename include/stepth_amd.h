@@ -187,8 +187,9 @@ int stepth_adaptive_groups(stepth_engine *engine, const stepth_image *main,
  * small frame or row strip cannot fill the GPU -- the cost of a query varies by two orders of
  * magnitude and one heavy query is a ~100 us critical path -- so callers with several frames
  * in flight (video, row-strip sharding of many frames) should batch them.
- *   - ring mode, uniform 1x1 tiles (one group per pixel), every frame the same sizes; params
- *     (rows, row pattern, flags) apply to every frame;
+ *   - ring mode with uniform 1x1 tiles (one group per pixel), or the windowed-SAD mode
+ *     (contiguous row strips only); every frame the same sizes; params (rows, row pattern,
+ *     flags) apply to every frame;
  *   - every image in device memory (same strides for every frame), or every image in host
  *     memory (what a caller holding decoded images in RAM has, src/depth_image.rs:8-9, :96).
  *     Host batches are synchronous and pipelined: chunks of frames are uploaded on a copy

@@ -650,11 +650,12 @@ int stepth_depth_from_additional(stepth_engine *e, const stepth_image *main_im,
         TRY(reserve(e, e->raw, (size_t)W * std::max(rows, 1u)));
         if (rows) {
             SadArgs sa{};
-            sa.left = d_main;
+            sa.left[0] = d_main;
             sa.lstride = ms;
             sa.lch = main_im->channels;
-            sa.right = d_add;
+            sa.right[0] = d_add;
             sa.rstride = as;
+            sa.n_frames = 1;
             sa.w = W;
             sa.h = H;
             sa.row0 = row0;
@@ -900,6 +901,101 @@ static int batch_host(stepth_engine *e, uint32_t n_frames, const stepth_image *m
                       const stepth_image *adds, const stepth_params &p, const stepth_image *depths,
                       uint32_t *max_out);
 
+// windowed-SAD mode for a batch of device frames: packs, searches and paints all frames of a
+// chunk in one launch each (blockIdx.z / .y = frame)
+static int batch_sad(stepth_engine *e, uint32_t n_frames, const stepth_image *mains,
+                     const stepth_image *adds, const stepth_params &p, const stepth_image *depths,
+                     uint32_t *max_out, uint32_t row0, uint32_t row1)
+{
+    const uint32_t W = mains[0].width, H = mains[0].height, rows = row1 - row0;
+    const bool async = p.flags & STEPTH_FLAG_ASYNC, raw_only = p.flags & STEPTH_FLAG_RAW_ONLY;
+    if (p.row_block)
+        return fail(e, STEPTH_ERR_BAD_ARG, "SAD mode: contiguous row strips only");
+    if (adds[0].width != W || adds[0].height != H)
+        return fail(e, STEPTH_ERR_SIZE_MISMATCH, "Sizes don't match: SAD mode needs equal image sizes");
+    if ((p.win & 1u) == 0 || p.win > 15 || p.d_max == 0 || p.d_max > 256)
+        return fail(e, STEPTH_ERR_BAD_ARG, "SAD mode: win must be odd <= 15, d_max in 1..256");
+    bool any_zero = false;
+    for (uint32_t f0 = 0; f0 < n_frames; f0 += kMaxBatch) {
+        const uint32_t nf = std::min<uint32_t>(kMaxBatch, n_frames - f0);
+        HIP_TRY(e, hipMemsetAsync(e->words, 0, kWordsBytes, e->stream));
+        SadArgs sa{};
+        for (uint32_t f = 0; f < nf; ++f) {
+            sa.left[f] = static_cast<const uint8_t *>(mains[f0 + f].data);
+            sa.right[f] = static_cast<const uint8_t *>(adds[f0 + f].data);
+        }
+        sa.lstride = mains[0].stride;
+        sa.lch = mains[0].channels;
+        sa.rstride = adds[0].stride;
+        sa.n_frames = nf;
+        sa.w = W;
+        sa.h = H;
+        sa.row0 = row0;
+        sa.row1 = row1;
+        sa.d_max = p.d_max;
+        sa.win = p.win;
+        sa.thr = p.win * p.win * ((uint32_t)p.precision[0] + p.precision[1] + p.precision[2]);
+        sa.raw_stride = ((size_t)W * rows + 3u) & ~(size_t)3u;
+        TRY(reserve(e, e->raw, sa.raw_stride * nf));
+        sa.raw = static_cast<uint8_t *>(e->raw.p);
+        sa.max_word = e->words;
+        if (sad_has_fast_path(sa.win)) {
+            uint32_t prow = 0;
+            int apron = 0;
+            sad_plane_dims(sa, false, sa.lpitch, prow, apron);
+            sa.lplane_stride = (size_t)sa.lpitch * prow;
+            TRY(reserve(e, e->sad_left, sa.lplane_stride * nf * 4));
+            sad_plane_dims(sa, true, sa.rpitch, prow, apron);
+            sa.rplane_stride = (size_t)sa.rpitch * prow;
+            TRY(reserve(e, e->sad_right, sa.rplane_stride * nf * 4));
+            sa.lp = (uint32_t *)e->sad_left.p;
+            sa.rp = (uint32_t *)e->sad_right.p;
+            if (launch_sad_pack(sa, e->stream) != STEPTH_OK)
+                return fail(e, STEPTH_ERR_HIP, "sad_pack launch failed");
+        }
+        {
+            KernelTimer t(e);
+            const int s = launch_sad(sa, e->stream);
+            if (s != STEPTH_OK)
+                return fail(e, s, "sad_match launch failed: %s", hipGetErrorString(hipGetLastError()));
+        }
+        PaintArgs pa{};
+        pa.raw = sa.raw;
+        pa.raw_stride = (uint32_t)sa.raw_stride;
+        pa.max_word = e->words;
+        pa.max_out = (async && max_out) ? max_out + f0 : nullptr;
+        pa.identity = raw_only;
+        for (uint32_t f = 0; f < nf; ++f)
+            pa.out[f] = static_cast<uint8_t *>(const_cast<void *>(depths[f0 + f].data));
+        pa.ostride = depths[0].stride;
+        pa.w = W;
+        pa.h = H;
+        pa.row_begin = row0;
+        pa.row_end = row1;
+        pa.rp = RowPattern{0u, 1u, 0u};
+        pa.tile_w = pa.tile_h = 1;
+        pa.gx = W;
+        pa.n = W * rows;
+        const size_t total = (size_t)rows * W;
+        hipLaunchKernelGGL(paint_tiles_kernel, dim3((uint32_t)std::min<size_t>((total + 255) / 256, 1024), nf),
+                           dim3(256), 0, e->stream, pa);
+        HIP_TRY(e, hipGetLastError());
+        if (!async) {
+            uint32_t mx[kMaxBatch];
+            HIP_TRY(e, hipMemcpyAsync(mx, e->words, 4 * nf, hipMemcpyDeviceToHost, e->stream));
+            HIP_TRY(e, hipStreamSynchronize(e->stream));
+            for (uint32_t f = 0; f < nf; ++f) {
+                if (max_out)
+                    max_out[f0 + f] = mx[f];
+                any_zero |= mx[f] == 0;
+            }
+        }
+    }
+    if (!async && any_zero && !raw_only)
+        return fail(e, STEPTH_ERR_MAX_ZERO, "a frame's distances are all 0; its output is all zero");
+    return STEPTH_OK;
+}
+
 int stepth_depth_from_additional_batch(stepth_engine *e, uint32_t n_frames,
                                        const stepth_image *mains, const stepth_image *adds,
                                        const stepth_params *pp, const stepth_image *depths,
@@ -912,10 +1008,11 @@ int stepth_depth_from_additional_batch(stepth_engine *e, uint32_t n_frames,
     if (n_frames == 0 || !mains || !adds || !depths)
         return fail(e, STEPTH_ERR_BAD_ARG, "empty batch or null image arrays");
     const stepth_params p = *pp;
-    if (p.mode != STEPTH_MODE_RING_FIRST_HIT || p.tile_w != 1 || p.tile_h != 1 ||
+    const bool sad = p.mode == STEPTH_MODE_SAD_WINDOW;
+    if ((!sad && (p.mode != STEPTH_MODE_RING_FIRST_HIT || p.tile_w != 1 || p.tile_h != 1)) ||
         (p.flags & STEPTH_FLAG_GAUSSIAN_TAIL))
         return fail(e, STEPTH_ERR_BAD_ARG,
-                    "batch: ring mode with 1x1 tiles only, no Gaussian tail");
+                    "batch: ring mode with 1x1 tiles or SAD mode, no Gaussian tail");
     uint32_t n_host = 0;
     for (uint32_t f = 0; f < n_frames; ++f) {
         TRY(check_image(e, &mains[f], "main", 3, 4));
@@ -961,6 +1058,8 @@ int stepth_depth_from_additional_batch(stepth_engine *e, uint32_t n_frames,
     HIP_TRY(e, hipSetDevice(e->device));
     const uint32_t rows = row1 - row0;
     bool any_zero = false;
+    if (sad)
+        return batch_sad(e, n_frames, mains, adds, p, depths, max_out, row0, row1);
 
     // frames per set of launches: at most kMaxBatch, and few enough that all their cells can be
     // indexed with 32 bits

@@ -27,16 +27,20 @@
 namespace stepth {
 
 struct SadArgs {
-    const uint8_t *left;  // main image, lch bytes per pixel
+    // one image pair per frame of a batch (blockIdx.z in the search kernels)
+    const uint8_t *left[kMaxBatch];  // main images, lch bytes per pixel
     size_t lstride;
     uint32_t lch;
-    const uint8_t *right; // additional image, RGB8
+    const uint8_t *right[kMaxBatch]; // additional images, RGB8
     size_t rstride;
+    uint32_t n_frames;
+    size_t raw_stride;                // bytes between the frames' raw maps
+    size_t lplane_stride, rplane_stride; // dwords between the frames' packed planes
     uint32_t w, h;
     uint32_t row0, row1;
     uint32_t d_max, win, thr;
-    uint8_t *raw; // [(row1-row0)][w]
-    uint32_t *max_word;
+    uint8_t *raw; // [frame][(row1-row0)][w]
+    uint32_t *max_word; // one word per frame
     // packed planes (sad_pack_kernel)
     uint32_t *lp, *rp;
     uint32_t lpitch, rpitch; // dwords
@@ -53,10 +57,11 @@ __device__ __forceinline__ uint32_t load_rgbx(const uint8_t *img, size_t stride,
 
 // plane[yy][xx] = RGBX(img[clamp(yy - rad)][clamp(xx - apron_l)])
 struct SadPackArgs {
-    const uint8_t *img;
+    const uint8_t *img[kMaxBatch]; // blockIdx.y = frame
+    size_t plane_stride;           // dwords between the frames' planes
     size_t stride;
     uint32_t ch, w, h;
-    int rad, apron_l;
+    int rad, apron_l, row0; // plane row r holds image row row0 - rad + r (clamped)
     uint32_t pitch, rows;
     uint32_t *plane;
 };
@@ -67,7 +72,8 @@ __global__ __launch_bounds__(256) void sad_pack_kernel(SadPackArgs a)
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (size_t)gridDim.x * blockDim.x) {
         const int yy = (int)(i / a.pitch), xx = (int)(i % a.pitch);
-        a.plane[i] = load_rgbx(a.img, a.stride, a.ch, xx - a.apron_l, yy - a.rad, a.w, a.h);
+        a.plane[(size_t)blockIdx.y * a.plane_stride + i] =
+            load_rgbx(a.img[blockIdx.y], a.stride, a.ch, xx - a.apron_l, yy - a.rad + a.row0, a.w, a.h);
     }
 }
 
@@ -94,11 +100,14 @@ __global__ __launch_bounds__(256) void sad_search_kernel(SadArgs a)
         s_best[wv][r][lane] = 0xffffffffu;
         s_pick[wv][r][lane] = 0u;
     }
-    // plane coordinates: image (x', y') sits at [y' + RAD][x' + apron_l]
-    const uint32_t *lcol = a.lp + x;                         // + i  -> L(x - RAD + i)
+    // plane coordinates: image (x', y') sits at [y' - row0 + RAD][x' + apron_l] (the planes hold
+    // only the rows the strip [row0, row1) reads)
+    const uint32_t f = blockIdx.z; // frame
+    const uint32_t *lcol = a.lp + (size_t)f * a.lplane_stride + x; // + i  -> L(x - RAD + i)
     for (int d0 = 0; d0 < (int)a.d_max; d0 += DC) {
         // + k -> R(x - RAD + i - d) with k = i + (DC-1-j), d = d0 + j
-        const uint32_t *rcol = a.rp + x + kSadPadD + ((int)a.d_max - 1) - d0 - (DC - 1);
+        const uint32_t *rcol = a.rp + (size_t)f * a.rplane_stride + x + kSadPadD + ((int)a.d_max - 1) -
+                               d0 - (DC - 1);
         uint32_t cost[DC], ring[WIN][DC];
 #pragma unroll
         for (int j = 0; j < DC; ++j) {
@@ -107,15 +116,15 @@ __global__ __launch_bounds__(256) void sad_search_kernel(SadArgs a)
             for (int s = 0; s < WIN; ++s)
                 ring[s][j] = 0;
         }
-        // input rows ys-RAD .. ys+nrows-1+RAD, i.e. plane rows ys .. ys+nrows-1+2*RAD
+        // input rows ys-RAD .. ys+nrows-1+RAD, i.e. plane rows ys-row0 .. ys-row0+nrows-1+2*RAD
         const int n_in = nrows + 2 * RAD;
         for (int t0 = 0; t0 < n_in; t0 += WIN) {
 #pragma unroll
             for (int s = 0; s < WIN; ++s) {
                 const int t = t0 + s;
                 if (t < n_in) { // uniform
-                    const uint32_t *lr = lcol + (size_t)(ys + t) * a.lpitch;
-                    const uint32_t *rr = rcol + (size_t)(ys + t) * a.rpitch;
+                    const uint32_t *lr = lcol + (size_t)(ys - (int)a.row0 + t) * a.lpitch;
+                    const uint32_t *rr = rcol + (size_t)(ys - (int)a.row0 + t) * a.rpitch;
                     uint32_t l[WIN], r[DC + WIN - 1];
 #pragma unroll
                     for (int i = 0; i < WIN; ++i)
@@ -164,7 +173,7 @@ __global__ __launch_bounds__(256) void sad_search_kernel(SadArgs a)
     if (x < (int)a.w) {
         for (int r = 0; r < nrows; ++r) {
             const uint32_t d = s_pick[wv][r][lane] & 0xffffu;
-            a.raw[(size_t)(ys - (int)a.row0 + r) * a.w + x] = (uint8_t)d;
+            a.raw[(size_t)f * a.raw_stride + (size_t)(ys - (int)a.row0 + r) * a.w + x] = (uint8_t)d;
             m = max(m, d & 0xffu);
         }
     }
@@ -172,7 +181,7 @@ __global__ __launch_bounds__(256) void sad_search_kernel(SadArgs a)
     for (int o = 32; o > 0; o >>= 1)
         m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
     if (lane == 0 && m)
-        atomicMax(a.max_word, m);
+        atomicMax(a.max_word + blockIdx.z, m);
 }
 
 // ---- generic fallback (any odd window up to 15): one thread per pixel, windows in LDS ----
@@ -191,11 +200,11 @@ __global__ __launch_bounds__(256) void sad_match_kernel(SadArgs a)
 
     for (int i = threadIdx.x; i < lw * th; i += blockDim.x) {
         const int r = i / lw, c = i % lw;
-        Lt[i] = load_rgbx(a.left, a.lstride, a.lch, x0 - rad + c, y0 - rad + r, a.w, a.h);
+        Lt[i] = load_rgbx(a.left[blockIdx.z], a.lstride, a.lch, x0 - rad + c, y0 - rad + r, a.w, a.h);
     }
     for (int i = threadIdx.x; i < rw * th; i += blockDim.x) {
         const int r = i / rw, c = i % rw;
-        Rt[i] = load_rgbx(a.right, a.rstride, 3, x0 - rad - ((int)a.d_max - 1) + c,
+        Rt[i] = load_rgbx(a.right[blockIdx.z], a.rstride, 3, x0 - rad - ((int)a.d_max - 1) + c,
                           y0 - rad + r, a.w, a.h);
     }
     __syncthreads();
@@ -227,14 +236,14 @@ __global__ __launch_bounds__(256) void sad_match_kernel(SadArgs a)
     }
     uint32_t m = 0;
     if (x < (int)a.w && y < (int)a.row1) {
-        a.raw[(size_t)(y - (int)a.row0) * a.w + x] = (uint8_t)best_d;
+        a.raw[(size_t)blockIdx.z * a.raw_stride + (size_t)(y - (int)a.row0) * a.w + x] = (uint8_t)best_d;
         m = best_d & 0xffu;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1)
         m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
     if ((threadIdx.x & 63) == 0 && m)
-        atomicMax(a.max_word, m);
+        atomicMax(a.max_word + blockIdx.z, m);
 }
 
 inline bool sad_has_fast_path(uint32_t win) { return win == 3 || win == 5 || win == 7 || win == 9; }
@@ -245,7 +254,7 @@ inline void sad_plane_dims(const SadArgs &a, bool right, uint32_t &pitch, uint32
     const int rad = (int)a.win / 2;
     apron_l = rad + (right ? (int)a.d_max - 1 + kSadPadD : 0);
     pitch = (uint32_t)(apron_l + (int)((a.w + 63u) / 64u * 64u) + rad + 64);
-    rows = a.h + 2u * (uint32_t)rad;
+    rows = (a.row1 - a.row0) + 2u * (uint32_t)rad; // only what the strip [row0,row1) reads
 }
 
 // pack both planes; a.lp/a.rp/pitches must already be set
@@ -253,12 +262,15 @@ inline int launch_sad_pack(const SadArgs &a, hipStream_t stream)
 {
     for (int side = 0; side < 2; ++side) {
         SadPackArgs p{};
-        p.img = side ? a.right : a.left;
+        for (uint32_t f = 0; f < a.n_frames; ++f)
+            p.img[f] = side ? a.right[f] : a.left[f];
+        p.plane_stride = side ? a.rplane_stride : a.lplane_stride;
         p.stride = side ? a.rstride : a.lstride;
         p.ch = side ? 3u : a.lch;
         p.w = a.w;
         p.h = a.h;
         p.rad = (int)a.win / 2;
+        p.row0 = (int)a.row0;
         uint32_t pitch, rows;
         sad_plane_dims(a, side != 0, pitch, rows, p.apron_l);
         p.pitch = pitch;
@@ -266,7 +278,7 @@ inline int launch_sad_pack(const SadArgs &a, hipStream_t stream)
         p.plane = side ? a.rp : a.lp;
         const size_t total = (size_t)pitch * rows;
         const uint32_t blocks = (uint32_t)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-        hipLaunchKernelGGL(sad_pack_kernel, dim3(blocks), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL(sad_pack_kernel, dim3(blocks, a.n_frames), dim3(256), 0, stream, p);
     }
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
@@ -276,8 +288,8 @@ inline int launch_sad(const SadArgs &a, hipStream_t stream)
     if (sad_has_fast_path(a.win)) {
         const uint32_t cols = (a.w + 255) / 256, rows = a.row1 - a.row0;
         // enough waves to fill 256 CUs x 12 wave slots with 16-row strips?
-        const bool tall = (size_t)cols * 4 * ((rows + 15) / 16) >= 6144;
-        const dim3 grid(cols, tall ? (rows + 15) / 16 : (rows + 7) / 8);
+        const bool tall = (size_t)cols * 4 * ((rows + 15) / 16) * a.n_frames >= 6144;
+        const dim3 grid(cols, tall ? (rows + 15) / 16 : (rows + 7) / 8, a.n_frames);
 #define STEPTH_SAD_LAUNCH(W, D)                                                               \
     do {                                                                                      \
         if (tall)                                                                             \
@@ -297,7 +309,8 @@ inline int launch_sad(const SadArgs &a, hipStream_t stream)
     const int rad = (int)a.win / 2;
     const int lw = kSadTileW + 2 * rad, rw = lw + (int)a.d_max - 1, th = kSadTileH + 2 * rad;
     const size_t lds = (size_t)(lw + rw) * th * 4;
-    dim3 grid((a.w + kSadTileW - 1) / kSadTileW, (a.row1 - a.row0 + kSadTileH - 1) / kSadTileH);
+    dim3 grid((a.w + kSadTileW - 1) / kSadTileW, (a.row1 - a.row0 + kSadTileH - 1) / kSadTileH,
+              a.n_frames);
     hipLaunchKernelGGL(sad_match_kernel, grid, dim3(256), lds, stream, a);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }

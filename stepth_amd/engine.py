@@ -237,12 +237,13 @@ class Engine:
         return out[: n.value].copy()
 
     def depth_from_additional_batch(self, mains, additionals, precision, *, max_steps: int = 255,
+                                    mode: int = L.MODE_RING_FIRST_HIT, d_max: int = 0, win: int = 0,
                                     rows: Optional[Tuple[int, int]] = None,
                                     row_pattern: Optional[Tuple[int, int, int]] = None,
                                     raw_only: bool = False, outs=None, max_out=None,
                                     asynchronous: bool = False):
         """stepth_depth_from_additional_batch: many frames of equal shape in one set of launches,
-        ring mode, one group per pixel.  Frames are CUDA uint8 tensors, or numpy arrays (host
+        ring mode with one group per pixel, or the windowed-SAD mode (`mode`, `d_max`, `win`).  Frames are CUDA uint8 tensors, or numpy arrays (host
         memory: uploaded, computed and downloaded in overlapping chunks; page-locked arrays
         from host_array() copy fastest).  Returns (outs, max): `outs` a list of [H,W] tensors
         / arrays; max a list of ints, or None with asynchronous=True (then `max_out` must be a
@@ -267,10 +268,11 @@ class Engine:
             keep += [k1, k2, k3]
         p = L.Params()
         p.struct_size = C.sizeof(L.Params)
-        p.mode = L.MODE_RING_FIRST_HIT
+        p.mode = mode
         p.precision = _u8x3(precision)
         p.max_steps = max_steps
         p.tile_w = p.tile_h = 1
+        p.d_max, p.win = d_max, win
         if rows is not None:
             p.row_begin, p.row_end = rows
         if row_pattern is not None:

@@ -215,9 +215,9 @@ class EngineStripWorker(StripWorker):
             self.engine.normalise_rows(rows, max_word, asynchronous=True, first_row=first_row,
                                        row_pattern=pattern)
 
-    # -- all frames of a step in one set of launches (ring mode, 1x1 tiles) ------------------
+    # -- all frames of a step in one set of launches (ring mode with 1x1 tiles, SAD mode) -----
     def can_batch(self) -> bool:
-        return self.kw["mode"] == 0 and tuple(self.kw["tile"]) == (1, 1)
+        return self.kw["mode"] == 1 or tuple(self.kw["tile"]) == (1, 1)
 
     def match_batch(self, frames, rows, pattern=None):
         """PASS 1 for every frame -> (list of raw views [r1-r0, W], max int32 [F])."""
@@ -230,7 +230,9 @@ class EngineStripWorker(StripWorker):
         mx = torch.zeros(len(frames), dtype=torch.int32, device=dev)
         if rows[1] > rows[0]:
             self.engine.depth_from_additional_batch(mains, adds, self.precision,
-                                                    max_steps=self.kw["max_steps"], rows=rows,
+                                                    max_steps=self.kw["max_steps"],
+                                                    mode=self.kw["mode"], d_max=self.kw["d_max"],
+                                                    win=self.kw["win"], rows=rows,
                                                     row_pattern=pattern, raw_only=True,
                                                     outs=fulls, max_out=mx, asynchronous=True)
         self.last_base = base  # [F, H, W]; lets the caller gather rows of all frames at once

@@ -78,3 +78,34 @@ def test_sad_randomised_small_cases(engine, oracle):
                 mx = max(mx, m)
         np.testing.assert_array_equal(raw, ref, err_msg=str((case, w, h, d_max, win, prec)))
         assert mx == int(ref.max())
+
+
+def test_sad_batch_equals_frame_by_frame(engine, oracle):
+    """stepth_depth_from_additional_batch in SAD mode: all frames packed, searched and painted
+    in one launch each -- whole frames, strips (planes hold only the strip's rows), host batch"""
+    import torch
+    from stepth_amd import MODE_SAD_WINDOW, synth
+    pairs = [synth.stereo_pair(203, 97, 24, seed=60 + i)[:2] for i in range(5)]
+    kw = dict(mode=MODE_SAD_WINDOW, d_max=24, win=5)
+    want = [oracle.sad_rows(l, r, 24, 5, [4, 4, 4]) for l, r in pairs]
+    dl = [torch.from_numpy(np.ascontiguousarray(l)).cuda() for l, _ in pairs]
+    dr = [torch.from_numpy(np.ascontiguousarray(r)).cuda() for _, r in pairs]
+    outs, mx = engine.depth_from_additional_batch(dl, dr, [4, 4, 4], raw_only=True, **kw)
+    for f in range(5):
+        assert np.array_equal(outs[f].cpu().numpy(), want[f]) and mx[f] == int(want[f].max()), f
+    outs, mx = engine.depth_from_additional_batch(dl, dr, [4, 4, 4], **kw)  # normalised per frame
+    for f in range(5):
+        m = int(want[f].max())
+        assert np.array_equal(outs[f].cpu().numpy(), (want[f].astype(np.uint32) * 255 // m).astype(np.uint8)), f
+    for rows in ((0, 31), (31, 70), (70, 97), (96, 97)):
+        outs, mx = engine.depth_from_additional_batch(dl, dr, [4, 4, 4], raw_only=True, rows=rows, **kw)
+        for f in range(5):
+            assert np.array_equal(outs[f].cpu().numpy()[rows[0]:rows[1]], want[f][rows[0]:rows[1]]), (f, rows)
+            assert mx[f] == int(want[f][rows[0]:rows[1]].max())
+    hl = [np.ascontiguousarray(l) for l, _ in pairs]
+    hr = [np.ascontiguousarray(r) for _, r in pairs]
+    outs, mx = engine.depth_from_additional_batch(hl, hr, [4, 4, 4], raw_only=True, win=9, mode=MODE_SAD_WINDOW, d_max=24)
+    for f in range(5):
+        assert np.array_equal(outs[f], oracle.sad_rows(hl[f], hr[f], 24, 9, [4, 4, 4])), f
+    with pytest.raises(Exception):  # interleaved patterns are a ring-mode feature
+        engine.depth_from_additional_batch(dl, dr, [4, 4, 4], row_pattern=(2, 2, 0), **kw)
