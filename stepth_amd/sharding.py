@@ -59,7 +59,7 @@ class StripBalancer:
         self.timed_bounds = None   # ... and the strips it was taken with
         self._open = None          # measurement being taken
         self._timings = collections.deque()  # GPU measurements not read yet
-        self.pending = None        # (all-reduced times tensor, their bounds) of the last call
+        self._pending = collections.deque()  # (all-reduced times, their bounds, event) per call
         self._updates = 0
 
     # -- timing of this rank's share (GPU events on the current stream, or the wall clock) --
@@ -96,11 +96,23 @@ class StripBalancer:
             self.last_ms, self.timed_bounds = a.elapsed_time(b), bounds
         return 0 if self.last_ms is None else max(1, int(self.last_ms * 1e3))
 
+    def push_pending(self, times: torch.Tensor, timed_bounds) -> None:
+        """the all-reduced times of this call (a tensor still being produced on the current
+        stream) and the strips they were measured with; read `lag` calls later"""
+        ev = None
+        if times.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record()
+        self._pending.append((times, timed_bounds, ev))
+
     def apply_pending(self) -> None:
-        """new cut points from the times all-reduced during the previous call"""
-        if self.pending is not None:
-            times, tb = self.pending
-            self.pending = None
+        """new cut points from the times all-reduced `lag` calls ago.  The event makes the
+        read safe when the calls alternate over streams (the reading stream is not the one that
+        ran the reduction) and identical on every rank."""
+        if len(self._pending) >= self.lag:
+            times, tb, ev = self._pending.popleft()
+            if ev is not None:
+                ev.synchronize()
             self.update([int(t) for t in times.tolist()], tb)
 
     def update(self, times_us: Sequence[int], timed_bounds=None) -> None:
@@ -365,8 +377,8 @@ def sharded_depth(worker: StripWorker, frames: Sequence, height: int, width: int
         else:
             dist.all_reduce(max_all, op=dist.ReduceOp.MAX, group=group)  # src/depth_image.rs:124
     if use_balancer:
-        # read on the next call, when the reduction has long finished: no host sync here
-        balancer.pending = (max_all[n:], balancer.timed_bounds)
+        # read `lag` calls later, when the reduction has long finished: no host sync here
+        balancer.push_pending(max_all[n:], balancer.timed_bounds)
         max_all = max_all[:n]
     if batched:  # src/depth_image.rs:125-129
         worker.normalise_batch(strips, max_all, first_row=r0, pattern=pattern)
