@@ -1,6 +1,8 @@
 """GPU parity of the reference-exact mode: the HIP path, called through the C-ABI
 (libstepth_amd.so), against the CPU oracle on the same inputs.  Bit-exact everywhere (u8
 depth, u32 distances, hit positions); integer work has no tolerance."""
+import os
+
 import numpy as np
 import pytest
 
@@ -729,3 +731,23 @@ def test_two_engines_on_two_threads(oracle):
     for t in ts:
         t.join(timeout=120)
     assert not errors, errors
+
+
+def test_multirank_rehearsal_on_the_engine():
+    """tests/tools/rehearse_multirank.py: 3 ranks (gloo) sharing this GPU run the sharded flow
+    on the real engine -- work-weighted strips, pipelined gather, steps alternating over two
+    streams -- and every frame of every step equals the single-process result"""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(ROOT, "tests", "tools", "rehearse_multirank.py")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+    assert "mismatching frames 0" in r.stdout and "identical on all ranks: True" in r.stdout
