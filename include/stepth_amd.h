@@ -196,6 +196,8 @@ int stepth_adaptive_groups(stepth_engine *engine, const stepth_image *main,
  *     stream while the previous chunk's kernels run and the one before downloads, so the PCIe
  *     transfers hide behind the kernels; page-locked memory (stepth_host_alloc) makes the
  *     copies fully asynchronous;
+ *   - STEPTH_FLAG_GAUSSIAN_TAIL (ring mode, whole frames, not RAW_ONLY) applies the same-size
+ *     Gaussian resample of src/depth_image.rs:133-134 to every frame, two launches per chunk;
  *   - n_frames is not limited (the engine works through it in chunks of 64);
  *   - max_out: n_frames words, device memory with STEPTH_FLAG_ASYNC, host memory otherwise
  *     (synchronous calls return STEPTH_ERR_MAX_ZERO if ANY frame's max is 0).

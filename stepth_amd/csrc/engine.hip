@@ -407,34 +407,47 @@ void gaussian_weights(float w[4][4][7])
 }
 
 // vertical pass src -> gauss_tmp, horizontal pass gauss_tmp -> dst (device pointers)
-int gaussian_device(stepth_engine *e, const uint8_t *src, size_t sstride, uint32_t w, uint32_t h,
-                    uint8_t *dst, size_t dstride)
+// same-size Gaussian resample of nf planes of one shape (src[f] -> dst[f], may be the same)
+int gaussian_device_batch(stepth_engine *e, uint32_t nf, const uint8_t *const *src, size_t sstride,
+                          uint32_t w, uint32_t h, uint8_t *const *dst, size_t dstride)
 {
-    TRY(reserve(e, e->gauss_tmp, (size_t)w * h));
+    const size_t plane = ((size_t)w * h + 15) & ~(size_t)15;
+    TRY(reserve(e, e->gauss_tmp, plane * nf));
     GaussArgs ga{};
     gaussian_weights(ga.w);
     const size_t total = (size_t)w * h;
-    const uint32_t blocks = (uint32_t)std::min<size_t>((total + 255) / 256, 4096);
-    ga.src = src;
+    const dim3 grid((uint32_t)std::min<size_t>((total + 255) / 256, 4096), nf);
+    uint8_t *tmp = static_cast<uint8_t *>(e->gauss_tmp.p);
+    for (uint32_t f = 0; f < nf; ++f) {
+        ga.src[f] = src[f];
+        ga.dst[f] = tmp + plane * f;
+    }
     ga.s_elem = sstride; // vertical_sample: along rows
     ga.s_line = 1;
     ga.n = h;
     ga.lines = w;
-    ga.dst = (uint8_t *)e->gauss_tmp.p;
     ga.d_elem = w;
     ga.d_line = 1;
-    hipLaunchKernelGGL(gauss_pass_kernel, dim3(blocks), dim3(256), 0, e->stream, ga);
-    ga.src = (const uint8_t *)e->gauss_tmp.p; // horizontal_sample
+    hipLaunchKernelGGL(gauss_pass_kernel, grid, dim3(256), 0, e->stream, ga);
+    for (uint32_t f = 0; f < nf; ++f) {
+        ga.src[f] = tmp + plane * f; // horizontal_sample
+        ga.dst[f] = dst[f];
+    }
     ga.s_elem = 1;
     ga.s_line = w;
     ga.n = w;
     ga.lines = h;
-    ga.dst = dst;
     ga.d_elem = 1;
     ga.d_line = dstride;
-    hipLaunchKernelGGL(gauss_pass_kernel, dim3(blocks), dim3(256), 0, e->stream, ga);
+    hipLaunchKernelGGL(gauss_pass_kernel, grid, dim3(256), 0, e->stream, ga);
     HIP_TRY(e, hipGetLastError());
     return STEPTH_OK;
+}
+
+int gaussian_device(stepth_engine *e, const uint8_t *src, size_t sstride, uint32_t w, uint32_t h,
+                    uint8_t *dst, size_t dstride)
+{
+    return gaussian_device_batch(e, 1, &src, sstride, w, h, &dst, dstride);
 }
 
 } // namespace
@@ -1009,10 +1022,13 @@ int stepth_depth_from_additional_batch(stepth_engine *e, uint32_t n_frames,
         return fail(e, STEPTH_ERR_BAD_ARG, "empty batch or null image arrays");
     const stepth_params p = *pp;
     const bool sad = p.mode == STEPTH_MODE_SAD_WINDOW;
-    if ((!sad && (p.mode != STEPTH_MODE_RING_FIRST_HIT || p.tile_w != 1 || p.tile_h != 1)) ||
-        (p.flags & STEPTH_FLAG_GAUSSIAN_TAIL))
+    if (!sad && (p.mode != STEPTH_MODE_RING_FIRST_HIT || p.tile_w != 1 || p.tile_h != 1))
+        return fail(e, STEPTH_ERR_BAD_ARG, "batch: ring mode with 1x1 tiles or SAD mode");
+    const bool gauss_tail = p.flags & STEPTH_FLAG_GAUSSIAN_TAIL;
+    if (gauss_tail && (sad || (p.flags & STEPTH_FLAG_RAW_ONLY) || p.row_block ||
+                       !(p.row_begin == 0 && (p.row_end == 0 || p.row_end == mains[0].height))))
         return fail(e, STEPTH_ERR_BAD_ARG,
-                    "batch: ring mode with 1x1 tiles or SAD mode, no Gaussian tail");
+                    "STEPTH_FLAG_GAUSSIAN_TAIL needs whole normalised ring-mode frames");
     uint32_t n_host = 0;
     for (uint32_t f = 0; f < n_frames; ++f) {
         TRY(check_image(e, &mains[f], "main", 3, 4));
@@ -1149,6 +1165,8 @@ int stepth_depth_from_additional_batch(stepth_engine *e, uint32_t n_frames,
         else
             hipLaunchKernelGGL(paint_tiles_kernel, grid, dim3(256), 0, e->stream, pa);
         HIP_TRY(e, hipGetLastError());
+        if (gauss_tail) // src/depth_image.rs:133-134, in place on the painted maps
+            TRY(gaussian_device_batch(e, nf, pa.out, pa.ostride, W, H, pa.out, pa.ostride));
 
         if (!async) {
             uint32_t mx[kMaxBatch];

@@ -1062,10 +1062,10 @@ __global__ __launch_bounds__(256) void normalise_rows_kernel(NormArgs a)
 // use the very same floats.
 // ---------------------------------------------------------------------------------------
 struct GaussArgs {
-    const uint8_t *src;
+    const uint8_t *src[kMaxBatch]; // one plane per frame (blockIdx.y)
     size_t s_elem, s_line; // strides along the filtered axis / between lines
     uint32_t n, lines;
-    uint8_t *dst;
+    uint8_t *dst[kMaxBatch];
     size_t d_elem, d_line;
     float w[4][4][7]; // [clipped taps before][clipped taps after][offset + 3]
 };
@@ -1076,6 +1076,8 @@ __global__ __launch_bounds__(256) void gauss_pass_kernel(GaussArgs a)
 // __fadd_rn are plain operators, so contraction into FMA has to be switched off here
 #pragma clang fp contract(off)
     const size_t total = (size_t)a.n * a.lines;
+    const uint8_t *src = a.src[blockIdx.y];
+    uint8_t *dst = a.dst[blockIdx.y];
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (size_t)gridDim.x * blockDim.x) {
         // consecutive threads run along the contiguous direction of the destination
@@ -1085,11 +1087,11 @@ __global__ __launch_bounds__(256) void gauss_pass_kernel(GaussArgs a)
         const float *w = a.w[min(cl, 3)][min(cr, 3)];
         float t = 0.0f;
         for (int k = cl - 3; k <= 3 - cr; ++k) {
-            const float v = (float)a.src[(size_t)l * a.s_line + (size_t)((int)o + k) * a.s_elem];
+            const float v = (float)src[(size_t)l * a.s_line + (size_t)((int)o + k) * a.s_elem];
             t = t + v * w[k + 3];
         }
         t = fminf(fmaxf(t, 0.0f), 255.0f);
-        a.dst[(size_t)l * a.d_line + (size_t)o * a.d_elem] = (uint8_t)roundf(t);
+        dst[(size_t)l * a.d_line + (size_t)o * a.d_elem] = (uint8_t)roundf(t);
     }
 }
 

@@ -240,8 +240,8 @@ class Engine:
                                     mode: int = L.MODE_RING_FIRST_HIT, d_max: int = 0, win: int = 0,
                                     rows: Optional[Tuple[int, int]] = None,
                                     row_pattern: Optional[Tuple[int, int, int]] = None,
-                                    raw_only: bool = False, outs=None, max_out=None,
-                                    asynchronous: bool = False):
+                                    raw_only: bool = False, gaussian_tail: bool = False,
+                                    outs=None, max_out=None, asynchronous: bool = False):
         """stepth_depth_from_additional_batch: many frames of equal shape in one set of launches,
         ring mode with one group per pixel, or the windowed-SAD mode (`mode`, `d_max`, `win`).  Frames are CUDA uint8 tensors, or numpy arrays (host
         memory: uploaded, computed and downloaded in overlapping chunks; page-locked arrays
@@ -277,7 +277,8 @@ class Engine:
             p.row_begin, p.row_end = rows
         if row_pattern is not None:
             p.row_block, p.row_mod, p.row_rem = row_pattern
-        p.flags = (L.FLAG_ASYNC if asynchronous else 0) | (L.FLAG_RAW_ONLY if raw_only else 0)
+        p.flags = ((L.FLAG_ASYNC if asynchronous else 0) | (L.FLAG_RAW_ONLY if raw_only else 0) |
+                   (L.FLAG_GAUSSIAN_TAIL if gaussian_tail else 0))
         if asynchronous:
             mptr = max_out.data_ptr() if max_out is not None else None
             self._check(self._lib.stepth_depth_from_additional_batch(self._h, n, mi, ai,

@@ -751,3 +751,26 @@ def test_multirank_rehearsal_on_the_engine():
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
     assert "mismatching frames 0" in r.stdout and "identical on all ranks: True" in r.stdout
+
+
+def test_batch_with_gaussian_tail(engine, oracle):
+    """STEPTH_FLAG_GAUSSIAN_TAIL in the batch entry: the reference's complete output (depth map +
+    same-size Gaussian resample, src/depth_image.rs:125-134) for many frames, device and host"""
+    import torch
+    from stepth_amd import synth
+    pairs = [synth.stereo_pair(161, 90, 24, seed=300 + i)[:2] for i in range(5)]
+    want = [oracle.gaussian_same_size(oracle.depth_from_additional(l, r, [36] * 3, 60)["depth"]) for l, r in pairs]
+    dl = [torch.from_numpy(np.ascontiguousarray(l)).cuda() for l, _ in pairs]
+    dr = [torch.from_numpy(np.ascontiguousarray(r)).cuda() for _, r in pairs]
+    outs, _mx = engine.depth_from_additional_batch(dl, dr, [36] * 3, max_steps=60, gaussian_tail=True)
+    for f in range(5):
+        assert np.array_equal(outs[f].cpu().numpy(), want[f]), f
+    hl = [np.ascontiguousarray(l) for l, _ in pairs]
+    hr = [np.ascontiguousarray(r) for _, r in pairs]
+    outs, _mx = engine.depth_from_additional_batch(hl, hr, [36] * 3, max_steps=60, gaussian_tail=True)
+    for f in range(5):
+        assert np.array_equal(outs[f], want[f]), f
+    with pytest.raises(Exception):  # the tail needs whole normalised frames
+        engine.depth_from_additional_batch(dl, dr, [36] * 3, gaussian_tail=True, rows=(0, 40))
+    with pytest.raises(Exception):
+        engine.depth_from_additional_batch(dl, dr, [36] * 3, gaussian_tail=True, raw_only=True)
