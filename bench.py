@@ -355,6 +355,23 @@ def main():
                 "hbm_frac": round(ALGO_BYTES_PER_PIXEL * W * H * min(n_frames, 64)
                                   / (sms / max(sl, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)}
         if args.mode == "ring" and world == 1:
+            # the reference's complete output: depth map + same-size Gaussian resample
+            # (src/depth_image.rs:133-134; image 0.23.14's sampler restated, parity unpinned)
+            mains_t, adds_t = [f[0] for f in frames], [f[1] for f in frames]
+            outs_t = [torch.empty((H, W), dtype=torch.uint8, device=dev) for _ in frames]
+            eng.depth_from_additional_batch(mains_t, adds_t, prec, max_steps=args.d_max,
+                                            gaussian_tail=True, outs=outs_t, asynchronous=True)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                eng.depth_from_additional_batch(mains_t, adds_t, prec, max_steps=args.d_max,
+                                                gaussian_tail=True, outs=outs_t, asynchronous=True)
+            torch.cuda.synchronize()
+            gdt = (time.perf_counter() - t1) / 3
+            out["with_gaussian_tail"] = {
+                "value": round(px_step / gdt / 1e6, 1), "unit": "Mpixels/s",
+                "workload": "same frames, depth map + same-size Gaussian resample, one stream"}
+        if args.mode == "ring" and world == 1:
             # README's second half on the depth maps of the last step (Readme.md:18-24):
             # select_foreground = histogram + depth_split(2) + slice, three launches for all
             # frames; 1 B read twice + 1 B written per pixel.  Outside the timed region.
