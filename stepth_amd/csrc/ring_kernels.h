@@ -1075,14 +1075,15 @@ __global__ __launch_bounds__(256) void gauss_pass_kernel(GaussArgs a)
 // the reference accumulates t += v * w in f32 with separate roundings; HIP's __fmul_rn /
 // __fadd_rn are plain operators, so contraction into FMA has to be switched off here
 #pragma clang fp contract(off)
-    const size_t total = (size_t)a.n * a.lines;
+    const uint32_t total = a.n * a.lines; // sides are <= 65535: fits 32 bits
     const uint8_t *src = a.src[blockIdx.y];
     uint8_t *dst = a.dst[blockIdx.y];
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (size_t)gridDim.x * blockDim.x) {
+    const uint32_t inner = a.d_elem == 1 ? a.n : a.lines; // extent of the contiguous direction
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         // consecutive threads run along the contiguous direction of the destination
-        const uint32_t o = a.d_elem == 1 ? (uint32_t)(i % a.n) : (uint32_t)(i / a.lines);
-        const uint32_t l = a.d_elem == 1 ? (uint32_t)(i / a.n) : (uint32_t)(i % a.lines);
+        const uint32_t q = i / inner, rem = i - q * inner;
+        const uint32_t o = a.d_elem == 1 ? rem : q;
+        const uint32_t l = a.d_elem == 1 ? q : rem;
         const int cl = max(0, 3 - (int)o), cr = max(0, (int)o + 3 - (int)(a.n - 1));
         const float *w = a.w[min(cl, 3)][min(cr, 3)];
         float t = 0.0f;
