@@ -18,6 +18,11 @@
  *   - disage grouping (rgb_discrete), to_luma8_from_rgb8 and image 0.23.14's Gaussian
  *     resample: source absent, no fixture -> "parity unpinned"; groups are an explicit input
  *     here (uniform tiles or a caller-supplied rectangle list).
+ *   - depth_split / select_foreground / slice / invert_depth / apply_mask: restated item by item
+ *     from src/depth_image.rs:162-247 and src/mask_image.rs:205-213; pinned by tolerance against
+ *     the reference's second shipped result, assets/foreground.jpg (tests/test_oracle_zones.py).
+ *   - oracle_adaptive_groups is this project's own stand-in for disage's grouping (parity
+ *     unpinned by construction).
  *   - the windowed-SAD mode has no counterpart in the reference at all (self-oracle).
  *
  * All citations are relative to /root/reference.
