@@ -774,3 +774,30 @@ def test_batch_with_gaussian_tail(engine, oracle):
         engine.depth_from_additional_batch(dl, dr, [36] * 3, gaussian_tail=True, rows=(0, 40))
     with pytest.raises(Exception):
         engine.depth_from_additional_batch(dl, dr, [36] * 3, gaussian_tail=True, raw_only=True)
+
+
+def test_batch_rgba_mains_unequal_additional_and_per_channel_precision(engine, oracle):
+    """batch entry on what DepthImage really holds -- RGBA mains (src/depth_image.rs:8) with
+    padded rows -- against additional images of another size, per-channel precision, 70 frames
+    (two chunks of the 64-frame launch)"""
+    import torch
+    rng = np.random.default_rng(77)
+    mains, adds = [], []
+    for i in range(7):
+        mains.append((rng.integers(0, 256, (41, 67, 3)) // 40 * 40).astype(np.uint8))
+        adds.append((rng.integers(0, 256, (58, 35, 3)) // 40 * 40).astype(np.uint8))
+    prec = [30, 50, 9]
+    refs = [oracle.depth_from_additional(m, a, prec, 255) for m, a in zip(mains, adds)]
+    rgba_store = [torch.zeros((41, 72, 4), dtype=torch.uint8, device="cuda") for _ in mains]
+    dm = []
+    for st, m in zip(rgba_store, mains):
+        st[:, :67, :3] = torch.from_numpy(m).cuda()
+        st[:, :67, 3] = 200
+        dm.append(st[:, :67])                     # row stride 72*4 bytes, 4 channels
+    da = [torch.from_numpy(a).cuda() for a in adds]
+    many_m, many_a = [dm[i % 7] for i in range(70)], [da[i % 7] for i in range(70)]
+    outs, mx = engine.depth_from_additional_batch(many_m, many_a, prec)
+    for i in range(70):
+        ref = refs[i % 7]
+        if ref["status"] == 0:
+            assert mx[i] == ref["max"] and np.array_equal(outs[i].cpu().numpy(), ref["depth"]), i
