@@ -413,6 +413,34 @@ int gaussian_device_batch(stepth_engine *e, uint32_t nf, const uint8_t *const *s
 {
     const size_t plane = ((size_t)w * h + 15) & ~(size_t)15;
     TRY(reserve(e, e->gauss_tmp, plane * nf));
+    // four pixels per thread when everything is dword aligned (the usual case)
+    bool vec4 = (w & 3u) == 0 && (sstride & 3u) == 0 && (dstride & 3u) == 0;
+    for (uint32_t f = 0; f < nf; ++f)
+        vec4 = vec4 && ((reinterpret_cast<uintptr_t>(src[f]) | reinterpret_cast<uintptr_t>(dst[f])) & 3u) == 0;
+    if (vec4) {
+        Gauss4Args g4{};
+        gaussian_weights(g4.wt);
+        g4.w = w;
+        g4.h = h;
+        uint8_t *tmp4 = static_cast<uint8_t *>(e->gauss_tmp.p);
+        const dim3 grid4((uint32_t)std::min<size_t>(((size_t)(w / 4) * h + 255) / 256, 4096), nf);
+        for (uint32_t f = 0; f < nf; ++f) {
+            g4.src[f] = src[f];
+            g4.dst[f] = tmp4 + plane * f;
+        }
+        g4.sstride = sstride;
+        g4.dstride = w;
+        hipLaunchKernelGGL(gauss_vertical4_kernel, grid4, dim3(256), 0, e->stream, g4);
+        for (uint32_t f = 0; f < nf; ++f) {
+            g4.src[f] = tmp4 + plane * f;
+            g4.dst[f] = dst[f];
+        }
+        g4.sstride = w;
+        g4.dstride = dstride;
+        hipLaunchKernelGGL(gauss_horizontal4_kernel, grid4, dim3(256), 0, e->stream, g4);
+        HIP_TRY(e, hipGetLastError());
+        return STEPTH_OK;
+    }
     GaussArgs ga{};
     gaussian_weights(ga.w);
     const size_t total = (size_t)w * h;

@@ -1096,6 +1096,84 @@ __global__ __launch_bounds__(256) void gauss_pass_kernel(GaussArgs a)
     }
 }
 
+// The same two passes, four outputs per thread with dword loads and stores (width a multiple of
+// 4, pointers and strides 4-byte aligned -- the host checks).  Every output accumulates its taps
+// in the same order with the same weights as gauss_pass_kernel, so the bytes are identical.
+struct Gauss4Args {
+    const uint8_t *src[kMaxBatch];
+    uint8_t *dst[kMaxBatch];
+    size_t sstride, dstride; // bytes between rows
+    uint32_t w, h;
+    float wt[4][4][7];
+};
+
+__device__ __forceinline__ uint32_t gauss_round(float t)
+{
+    t = fminf(fmaxf(t, 0.0f), 255.0f);
+    return (uint32_t)(uint8_t)roundf(t);
+}
+
+// vertical pass: out(x, y) = sum_k in(x, y + k) * w[k]; thread = 4 adjacent columns of one row
+__global__ __launch_bounds__(256) void gauss_vertical4_kernel(Gauss4Args a)
+{
+#pragma clang fp contract(off)
+    const uint32_t wq = a.w >> 2, total = wq * a.h;
+    const uint8_t *src = a.src[blockIdx.y];
+    uint8_t *dst = a.dst[blockIdx.y];
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const uint32_t y = i / wq, x = (i - y * wq) << 2;
+        const int cl = max(0, 3 - (int)y), cr = max(0, (int)y + 3 - (int)(a.h - 1));
+        const float *w = a.wt[min(cl, 3)][min(cr, 3)];
+        float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f, t3 = 0.0f;
+        for (int k = cl - 3; k <= 3 - cr; ++k) {
+            const uint32_t v = *reinterpret_cast<const uint32_t *>(src + (size_t)((int)y + k) * a.sstride + x);
+            const float wk = w[k + 3];
+            t0 = t0 + (float)(v & 255u) * wk;
+            t1 = t1 + (float)((v >> 8) & 255u) * wk;
+            t2 = t2 + (float)((v >> 16) & 255u) * wk;
+            t3 = t3 + (float)(v >> 24) * wk;
+        }
+        *reinterpret_cast<uint32_t *>(dst + (size_t)y * a.dstride + x) =
+            gauss_round(t0) | (gauss_round(t1) << 8) | (gauss_round(t2) << 16) | (gauss_round(t3) << 24);
+    }
+}
+
+// horizontal pass: out(x, y) = sum_k in(x + k, y) * w[k]; thread = outputs x .. x+3 of one row,
+// from the three aligned dwords around them
+__global__ __launch_bounds__(256) void gauss_horizontal4_kernel(Gauss4Args a)
+{
+#pragma clang fp contract(off)
+    const uint32_t wq = a.w >> 2, total = wq * a.h;
+    const uint8_t *src = a.src[blockIdx.y];
+    uint8_t *dst = a.dst[blockIdx.y];
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const uint32_t y = i / wq, q = i - y * wq, x = q << 2;
+        const uint32_t *row = reinterpret_cast<const uint32_t *>(src + (size_t)y * a.sstride);
+        const uint32_t d0 = q > 0 ? row[q - 1] : 0u, d1 = row[q], d2 = q + 1 < wq ? row[q + 1] : 0u;
+        float b[12]; // b[j] = in(x - 4 + j, y)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            b[j] = (float)((d0 >> (8 * j)) & 255u);
+            b[4 + j] = (float)((d1 >> (8 * j)) & 255u);
+            b[8 + j] = (float)((d2 >> (8 * j)) & 255u);
+        }
+        uint32_t out = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int o = (int)x + j;
+            const int cl = max(0, 3 - o), cr = max(0, o + 3 - (int)(a.w - 1));
+            const float *w = a.wt[min(cl, 3)][min(cr, 3)];
+            float t = 0.0f;
+#pragma unroll
+            for (int k = -3; k <= 3; ++k)
+                if (k >= cl - 3 && k <= 3 - cr)
+                    t = t + b[4 + j + k] * w[k + 3];
+            out |= gauss_round(t) << (8 * j);
+        }
+        *reinterpret_cast<uint32_t *>(dst + (size_t)y * a.dstride + x) = out;
+    }
+}
+
 __global__ void zero_words_kernel(uint32_t *p, int n)
 {
     if ((int)threadIdx.x < n)

@@ -472,7 +472,8 @@ def test_depth_image_mirror_end_to_end(engine, oracle, asset, tmp_path):
     np.testing.assert_array_equal(img.depth, ref["depth"])
 
 
-@pytest.mark.parametrize("w,h", [(600, 400), (1, 1), (3, 2), (2, 9), (64, 7), (257, 131)])
+@pytest.mark.parametrize("w,h", [(600, 400), (1, 1), (3, 2), (2, 9), (64, 7), (257, 131), (4, 1), (4, 5),
+                                 (8, 3), (12, 40), (1920, 16)])
 def test_gaussian_tail_matches_oracle(engine, oracle, w, h):
     rng = np.random.default_rng(w * 31 + h)
     img = rng.integers(0, 256, (h, w), dtype=np.uint8)
@@ -484,6 +485,14 @@ def test_gaussian_tail_matches_oracle(engine, oracle, w, h):
     engine.gaussian_same_size(strided[:, :w], out=out[:, :w])
     np.testing.assert_array_equal(out[:, :w], oracle.gaussian_same_size(img))
     assert (out[:, w:] == 9).all()
+    # device planes: aligned ones take the 4-pixels-per-thread kernels, offset ones the scalar one
+    import torch
+    t = torch.from_numpy(img).cuda()
+    np.testing.assert_array_equal(engine.gaussian_same_size(t).cpu().numpy(), oracle.gaussian_same_size(img))
+    wide = torch.zeros((h, w + 8), dtype=torch.uint8, device="cuda")
+    wide[:, 1:1 + w] = t
+    np.testing.assert_array_equal(engine.gaussian_same_size(wide[:, 1:1 + w]).cpu().numpy(),
+                                  oracle.gaussian_same_size(img))
 
 
 def test_gaussian_tail_flag_and_device_path(engine, oracle):
