@@ -30,7 +30,10 @@ def read_pgm(path):
 
 def test_cli_is_built_and_fails_loudly_without_a_device():
     import torch
-    assert os.path.exists(CLI), "run __graft_entry__.build()"
+    if not os.path.exists(CLI):  # a fresh checkout: same make as __graft_entry__.build()
+        from stepth_amd import _lib
+        _lib.build()
+    assert os.path.exists(CLI), "make -C stepth_amd/csrc did not produce the CLI"
     if torch.cuda.is_available():
         pytest.skip("GPU present")
     r = subprocess.run([CLI, "--check-errors"], capture_output=True, text=True)
