@@ -10,6 +10,16 @@ import pytest
 from conftest import ROOT
 
 CLI = os.path.join(ROOT, "stepth_amd", "stepth_depth_cli")
+CHECK = os.path.join(ROOT, "stepth_amd", "stepth_cabi_check")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built_programs():
+    """the two host programs are build products (git-ignored): make them if a checkout or a
+    snapshot came without them -- the same make as __graft_entry__.build()"""
+    if not (os.path.exists(CLI) and os.path.exists(CHECK)):
+        from stepth_amd import _lib
+        _lib.build()
 
 
 def write_pnm(path, a):
@@ -30,9 +40,6 @@ def read_pgm(path):
 
 def test_cli_is_built_and_fails_loudly_without_a_device():
     import torch
-    if not os.path.exists(CLI):  # a fresh checkout: same make as __graft_entry__.build()
-        from stepth_amd import _lib
-        _lib.build()
     assert os.path.exists(CLI), "make -C stepth_amd/csrc did not produce the CLI"
     if torch.cuda.is_available():
         pytest.skip("GPU present")
@@ -124,7 +131,5 @@ def test_cabi_check_program():
     """stepth_amd/csrc/cabi_check.cpp: every entry point of the C-ABI from plain C++ (host batch
     pipeline == single calls, device-resident adaptive groups -> list mode, consumers, SAD,
     tiles, Gaussian, page-locked memory)"""
-    exe = os.path.join(ROOT, "stepth_amd", "stepth_cabi_check")
-    assert os.path.exists(exe), "run __graft_entry__.build()"
-    r = subprocess.run([exe], capture_output=True, text=True, timeout=180)
+    r = subprocess.run([CHECK], capture_output=True, text=True, timeout=180)
     assert r.returncode == 0 and "CABI-CHECK-OK" in r.stdout, r.stdout + r.stderr
