@@ -17,6 +17,7 @@
 
 #include "../../include/stepth_amd.h"
 #include "ring_kernels.h"
+#include "tile_kernels.h"
 #include "sad_kernels.h"
 #include "zone_kernels.h"
 #include "group_kernels.h"
@@ -51,6 +52,8 @@ struct stepth_engine {
     std::string err;
 
     DevBuf T, BB, SB;      // packed additional image: tiled cells, block / superblock bounds
+    DevBuf TT, BBp, SBp;   // dense search (tile_kernels.h): column-major cells, padded bounds
+    uint32_t bbp_layout[3] = {0, 0, 0}; // bw, bh, frames the zero border of BBp was laid out for
     DevBuf stage_main, stage_add, stage_out, stage_groups;
     DevBuf queries, raw, aux32, aux_pos, aux_found, pending, pending_rec, pending_key;
     DevBuf sad_left, sad_right, gauss_tmp, gauss_io;
@@ -232,6 +235,148 @@ int pack_additional(stepth_engine *e, uint32_t n_frames, const uint8_t *const *d
                  sbw * sbh};
     hipLaunchKernelGGL(pack_super_kernel, dim3((sbw * sa.nsby + 3u) / 4u, n_frames), dim3(256), 0,
                        e->stream, sa);
+    HIP_TRY(e, hipGetLastError());
+    return STEPTH_OK;
+}
+
+// The dense search (tile_kernels.h) serves one group per pixel when the search fits its
+// superblock slots: rings up to 263 (the reference searches 255, depth_image.rs:119).
+bool tile_search_fits(uint32_t max_steps, uint32_t wa, uint32_t ha)
+{
+    return ((std::min(max_steps, std::max(wa, ha)) + 6u) >> 3) <= kSpiralRings;
+}
+
+// RGB8 additional images -> T, TT, padded block bounds, superblock bounds (tile_kernels.h)
+int pack_additional_tiles(stepth_engine *e, uint32_t n_frames, const uint8_t *const *d_adds,
+                          size_t stride, uint32_t wa, uint32_t ha, uint32_t &bw, uint32_t &bh,
+                          uint32_t row_lo, uint32_t row_hi)
+{
+    bw = (wa + 7u) / 8u;
+    bh = (ha + 7u) / 8u;
+    const size_t nblk = (size_t)bw * bh;
+    if (nblk * 64 * n_frames > 0x3FFFFFFFull)
+        return fail(e, STEPTH_ERR_BAD_ARG, "additional image %ux%u x %u frames exceeds 2^30 cells",
+                    wa, ha, n_frames);
+    const uint32_t sbw = (bw + 7u) / 8u, sbh = (bh + 7u) / 8u;
+    const uint32_t bwp = tile_bwp(bw), bhp = tile_bhp(bh), sbwp = tile_sbwp(sbw);
+    const size_t bb_frame = (size_t)bwp * bhp, sb_frame = (size_t)sbwp * sbh;
+    TRY(reserve(e, e->T, nblk * 64 * 4 * n_frames));
+    TRY(reserve(e, e->TT, nblk * 64 * 4 * n_frames));
+    const size_t bbp_cap = e->BBp.cap;
+    TRY(reserve(e, e->BBp, bb_frame * 8 * n_frames));
+    TRY(reserve(e, e->SBp, sb_frame * 8 * n_frames));
+    if (e->BBp.cap != bbp_cap || e->bbp_layout[0] != bw || e->bbp_layout[1] != bh ||
+        e->bbp_layout[2] < n_frames) {
+        // the border around the image's blocks must be empty bounds (all zero, never matching)
+        HIP_TRY(e, hipMemsetAsync(e->BBp.p, 0, bb_frame * 8 * n_frames, e->stream));
+        e->bbp_layout[0] = bw;
+        e->bbp_layout[1] = bh;
+        e->bbp_layout[2] = n_frames;
+    }
+    row_hi = std::min(row_hi, ha);
+    row_lo = std::min(row_lo, row_hi);
+    // (a strip that reaches no row at all still packs one, so that the launches are never empty)
+    const uint32_t by0 = std::min(row_lo / 8u, bh - 1u);
+    const uint32_t by1 = std::min(std::max((row_hi + 7u) / 8u, by0 + 1u), bh);
+    TilePackArgs pa{};
+    for (uint32_t f = 0; f < n_frames; ++f)
+        pa.src[f] = d_adds[f];
+    pa.stride = stride;
+    pa.wa = wa;
+    pa.ha = ha;
+    pa.bw = bw;
+    pa.bh = bh;
+    pa.bwp = bwp;
+    pa.T = (uint32_t *)e->T.p;
+    pa.TT = (uint32_t *)e->TT.p;
+    pa.BBp = (uint2 *)e->BBp.p;
+    pa.by0 = by0;
+    pa.nby = by1 - by0;
+    pa.zero = e->words;
+    pa.n_zero = (uint32_t)(kWordsBytes / 4);
+    pa.t_stride = (uint32_t)(nblk * 64);
+    pa.bb_stride = (uint32_t)bb_frame;
+    hipLaunchKernelGGL(tile_pack_kernel, dim3((bw * pa.nby + 3u) / 4u, n_frames), dim3(256), 0,
+                       e->stream, pa);
+    TileSuperArgs sa{};
+    sa.BBp = pa.BBp;
+    sa.bw = bw;
+    sa.bh = bh;
+    sa.bwp = bwp;
+    sa.sbw = sbw;
+    sa.sbwp = sbwp;
+    sa.SBp = (uint2 *)e->SBp.p;
+    sa.sby0 = by0 / 8u;
+    sa.nsby = (by1 + 7u) / 8u - by0 / 8u;
+    sa.by0 = by0;
+    sa.by1 = by1;
+    sa.bb_stride = pa.bb_stride;
+    sa.sb_stride = (uint32_t)sb_frame;
+    hipLaunchKernelGGL(tile_super_kernel, dim3((sbw * sa.nsby + 3u) / 4u, n_frames), dim3(256), 0,
+                       e->stream, sa);
+    HIP_TRY(e, hipGetLastError());
+    return STEPTH_OK;
+}
+
+// PASS 1 for one group per pixel, all frames of a chunk in one launch (tile_kernels.h).
+// `ra` carries the geometry the ring0/search path would use (main images, strip, raw).
+int launch_tile(stepth_engine *e, const RingArgs &ra, uint32_t n_frames)
+{
+    const uint32_t rows = ra.row1 - ra.row0;
+    if (rows == 0 || ra.w == 0)
+        return STEPTH_OK;
+    TileArgs ta{};
+    ta.T = (const uint32_t *)e->T.p;
+    ta.TT = (const uint32_t *)e->TT.p;
+    ta.BBp = (const uint2 *)e->BBp.p;
+    ta.SBp = (const uint2 *)e->SBp.p;
+    ta.wa = ra.wa;
+    ta.ha = ra.ha;
+    ta.bw = ra.bw;
+    ta.bh = ra.bh;
+    ta.bwp = tile_bwp(ra.bw);
+    ta.sbwp = tile_sbwp(ra.sbw);
+    ta.t_stride = ra.bw * ra.bh * 64u;
+    ta.bb_stride = ta.bwp * tile_bhp(ra.bh);
+    ta.sb_stride = ta.sbwp * ra.sbh;
+    for (uint32_t f = 0; f < n_frames; ++f)
+        ta.main_px[f] = ra.main_px[f];
+    ta.mstride = ra.mstride;
+    ta.mch = ra.mch;
+    ta.w = ra.w;
+    ta.row0 = ra.row0;
+    ta.row1 = ra.row1;
+    ta.rp = ra.rp;
+    // centres of the strip's pixels: cx = (x+1)/2 in 0..w/2, cy = (y+1)/2 in (row0+1)/2..row1/2
+    ta.cbx_n = ((ra.w >> 1) + 8u) >> 3;
+    ta.cby0 = ((ra.row0 + 1u) >> 1) >> 3;
+    ta.cby_n = ((ra.row1 >> 1) >> 3) - ta.cby0 + 1u;
+    const uint64_t n_wg = (uint64_t)ta.cbx_n * ta.cby_n * n_frames;
+    if (n_wg > 0x7FFFFFF0ull)
+        return fail(e, STEPTH_ERR_BAD_ARG, "too many centre blocks in one launch");
+    ta.n_wg = (uint32_t)n_wg;
+    // a search never leaves the array: more steps than its longer side change nothing
+    ta.max_steps = std::min(ra.max_steps, std::max(ra.wa, ra.ha));
+    {
+        const uint32_t top = std::max(ta.max_steps, 2u) - 1u;
+        uint32_t pb = 1;
+        while ((2u * top) >> pb)
+            ++pb;
+        ta.pos_bits = pb;
+    }
+    memcpy(ta.prec, ra.prec, 3);
+    ta.raw = ra.raw;
+    ta.raw_stride = (uint32_t)(((size_t)ra.n + 3u) & ~(size_t)3u);
+    ta.max_word = ra.max_word;
+    ta.stats = e->stats_enabled ? e->stats : nullptr;
+    const dim3 grid((ta.n_wg + 7u) & ~7u), block(256);
+    {
+        KernelTimer t(e); // the dominant kernel (bench.py's roofline leg)
+        if (e->stats_enabled)
+            hipLaunchKernelGGL(ring_tile_kernel<true>, grid, block, 0, e->stream, ta);
+        else
+            hipLaunchKernelGGL(ring_tile_kernel<false>, grid, block, 0, e->stream, ta);
+    }
     HIP_TRY(e, hipGetLastError());
     return STEPTH_OK;
 }
@@ -538,7 +683,7 @@ void stepth_engine_destroy(stepth_engine *e)
         return;
     (void)hipSetDevice(e->device);
     (void)hipStreamSynchronize(e->stream);
-    for (DevBuf *b : {&e->T, &e->BB, &e->SB, &e->spiral, &e->stage_main, &e->stage_add, &e->stage_out,
+    for (DevBuf *b : {&e->T, &e->BB, &e->SB, &e->TT, &e->BBp, &e->SBp, &e->spiral, &e->stage_main, &e->stage_add, &e->stage_out,
                       &e->stage_groups, &e->queries, &e->raw, &e->aux32, &e->aux_pos,
                       &e->aux_found, &e->pending, &e->pending_rec, &e->pending_key, &e->sad_left, &e->sad_right, &e->gauss_tmp, &e->gauss_io,
                       &e->zone_counts, &e->zone_tables, &e->pipe_main[0], &e->pipe_main[1],
@@ -746,6 +891,7 @@ int stepth_depth_from_additional(stepth_engine *e, const stepth_image *main_im,
         }
     } else if (p.mode == STEPTH_MODE_RING_FIRST_HIT) {
         uint32_t bw = 0, bh = 0;
+        bool use_tile = false; // one group per pixel: the dense search (tile_kernels.h)
         {
             // rows of the additional image the strip's searches can reach: the centres of
             // uniform tiles lie in rows [row0/2, (row1+tile_h)/2], every search stays within
@@ -757,7 +903,12 @@ int stepth_depth_from_additional(stepth_engine *e, const stepth_image *main_im,
                 lo = c_lo > reach ? c_lo - reach : 0u;
                 hi = c_hi + reach + 1u;
             }
-            TRY(pack_additional(e, 1, &d_add, as, add_im->width, add_im->height, bw, bh, lo, hi));
+            use_tile = !groups && p.tile_w == 1 && p.tile_h == 1 &&
+                       tile_search_fits(p.max_steps, add_im->width, add_im->height);
+            if (use_tile)
+                TRY(pack_additional_tiles(e, 1, &d_add, as, add_im->width, add_im->height, bw, bh, lo, hi));
+            else
+                TRY(pack_additional(e, 1, &d_add, as, add_im->width, add_im->height, bw, bh, lo, hi));
         }
 
         RingArgs ra{};
@@ -883,7 +1034,10 @@ int stepth_depth_from_additional(stepth_engine *e, const stepth_image *main_im,
             HIP_TRY(e, hipMemsetAsync(e->stats, 0, 64, e->stream));
             e->stats_groups = ra.n;
         }
-        TRY(launch_ring(e, ra, qmode));
+        if (use_tile)
+            TRY(launch_tile(e, ra, 1));
+        else
+            TRY(launch_ring(e, ra, qmode));
 
         pa.raw = ra.raw;
         pa.groups = d_groups;
@@ -1123,8 +1277,13 @@ int stepth_depth_from_additional_batch(stepth_engine *e, uint32_t n_frames,
             lo = row0 / 2u > reach ? row0 / 2u - reach : 0u;
             hi = (row1 + 1u) / 2u + reach + 1u;
         }
-        TRY(pack_additional(e, nf, d_adds, adds[0].stride, adds[0].width, adds[0].height, bw, bh,
-                            lo, hi));
+        const bool use_tile = tile_search_fits(p.max_steps, adds[0].width, adds[0].height);
+        if (use_tile)
+            TRY(pack_additional_tiles(e, nf, d_adds, adds[0].stride, adds[0].width, adds[0].height,
+                                      bw, bh, lo, hi));
+        else
+            TRY(pack_additional(e, nf, d_adds, adds[0].stride, adds[0].width, adds[0].height, bw, bh,
+                                lo, hi));
 
         RingArgs ra{};
         ra.T = (const uint32_t *)e->T.p;
@@ -1163,7 +1322,9 @@ int stepth_depth_from_additional_batch(stepth_engine *e, uint32_t n_frames,
             HIP_TRY(e, hipMemsetAsync(e->stats, 0, 64, e->stream));
             e->stats_groups = (uint64_t)ra.n * nf;
         }
-        if (ra.n_slots)
+        if (use_tile)
+            TRY(launch_tile(e, ra, nf));
+        else if (ra.n_slots)
             TRY(launch_ring(e, ra, 0, nf));
 
         PaintArgs pa{};

@@ -1,0 +1,411 @@
+// tile_kernels.h -- gfx950 dense ring search, "lane = query" (round 2).
+//
+// Path replaced: PASS 1 of DepthImage::load_depth_from_additional with one group per pixel,
+// /root/reference/src/depth_image.rs:112-123, and helpers::distance_dot_array,
+// /root/reference/src/helpers.rs:9-54.  One launch does ring 0, the search, the distance and
+// the per-frame max: no pending lists, no second pass over the queries.
+//
+// Why this shape.  The round-1 kernel gave one WAVE to the <= 4 queries that share a search
+// centre and spread the 64 blocks of a step over the lanes; it retired 123 VALU + 85 SALU
+// wave-instructions per pixel and was VALU-issue bound (a wave64 integer VALU instruction
+// holds its SIMD for ~3.9 cycles whatever the occupancy: tools/issue_microbench.hip,
+// profiles/r2_issue_microbench.txt).  Here one LANE owns one query:
+//
+//   workgroup = one 8x8 block of search centres of one frame = 16x16 main-image pixels
+//               (the four pixels 2cx-1..2cx x 2cy-1..2cy share the centre (cx,cy),
+//               depth_image.rs:114-117 with a 1x1 group); wave = 8x2 centres x 4 pixels.
+//   All 64 queries of a wave have their centre in the same 8x8-cell block of the additional
+//   image, so the wave walks ONE sequence of blocks: their bounds arrive by scalar loads
+//   (s_load_dwordx16 = a row of 8 blocks) and each lane tests them against its own colour box
+//   -- 5 VALU instructions per block for 64 queries, against ~70 per 64 blocks for <= 4
+//   queries before.  Blocks that pass are probed by the lane itself, a line of 8 cells at a
+//   time, nearest line first (tile_lane.h), with an early exit at the first hit.
+//
+//   step 0   the 7x7 blocks around the centre block (block-rings 0..3 = every cell of rings
+//            <= 24), probed block-ring by block-ring.  A query whose best ring is <= 24 is
+//            settled: every nearer cell was seen or excluded by bounds.
+//   survey   the others test the bounds of the 64x64-cell superblocks overlapping their
+//            window; the superblocks some lane wants go into lane slots keyed by distance.
+//   step k   nearest superblock first: its 64 block bounds (minus the 7x7 already done), the
+//            passing blocks probed block-ring by block-ring.  Every probe tightens the lane's
+//            `limit` (ring of its best key + 1); blocks and superblocks whose nearest cell is
+//            at ring >= limit are skipped -- the result is the exact first hit of the
+//            reference's scan order (tile_lane.h), bit for bit.
+//
+// Bounds are stored with a border of empty (all-zero = never matching) entries, so the block
+// windows need no edge cases.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ring_kernels.h"
+#include "tile_lane.h"
+
+namespace stepth {
+
+constexpr int kPadB = 4; // empty blocks left of / above the image in BBp
+// padded bounds layouts (host and device agree through these)
+STEPTH_HD uint32_t tile_bwp(uint32_t bw) { return ((bw + 7u) & ~7u) + 8u; }
+STEPTH_HD uint32_t tile_bhp(uint32_t bh) { return ((bh + 7u) & ~7u) + 8u; }
+STEPTH_HD uint32_t tile_sbwp(uint32_t sbw) { return sbw + 16u; } // rows are read 10 entries at a time
+
+struct TileArgs {
+    const uint32_t *T, *TT; // cells, 8x8 blocks: row-major / column-major inside a block
+    const uint2 *BBp;       // block bounds {max,min}, [bhp][bwp], image block (0,0) at (kPadB,kPadB)
+    const uint2 *SBp;       // superblock bounds, [sbh][sbwp]
+    uint32_t wa, ha, bw, bh, bwp, sbwp;
+    uint32_t t_stride, bb_stride, sb_stride; // per frame: dwords of T/TT, uint2 of BBp / SBp
+    const uint8_t *main_px[kMaxBatch];
+    size_t mstride;
+    uint32_t mch, w, row0, row1;
+    RowPattern rp;
+    uint32_t cbx_n, cby0, cby_n, n_wg; // centre blocks of the strip; workgroups that have work
+    uint32_t max_steps, pos_bits;
+    uint8_t prec[3];
+    uint8_t *raw; // (d as u8) per pixel of the strip, depth_image.rs:121
+    uint32_t raw_stride;
+    uint32_t *max_word; // per frame, depth_image.rs:124
+    unsigned long long *stats;
+};
+
+__device__ __forceinline__ uint32_t rfl(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+
+// eight block-bound tests of one row, columns 7..0, shifted into `acc` (bit = column)
+__device__ __forceinline__ uint32_t test_row(uint32_t acc, const uint4 &v0, const uint4 &v1,
+                                             const uint4 &v2, const uint4 &v3, uint32_t lo,
+                                             uint32_t hi)
+{
+    acc = acc + acc + (box_meets(v3.z, v3.w, lo, hi) ? 1u : 0u);
+    acc = acc + acc + (box_meets(v3.x, v3.y, lo, hi) ? 1u : 0u);
+    acc = acc + acc + (box_meets(v2.z, v2.w, lo, hi) ? 1u : 0u);
+    acc = acc + acc + (box_meets(v2.x, v2.y, lo, hi) ? 1u : 0u);
+    acc = acc + acc + (box_meets(v1.z, v1.w, lo, hi) ? 1u : 0u);
+    acc = acc + acc + (box_meets(v1.x, v1.y, lo, hi) ? 1u : 0u);
+    acc = acc + acc + (box_meets(v0.z, v0.w, lo, hi) ? 1u : 0u);
+    acc = acc + acc + (box_meets(v0.x, v0.y, lo, hi) ? 1u : 0u);
+    return acc;
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(256) void ring_tile_kernel(TileArgs a)
+{
+    __shared__ uint32_t s_max[4];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wv = rfl(threadIdx.x >> 6);
+    // Workgroup ids go round-robin over the 8 XCDs; give every XCD one contiguous range of
+    // centre blocks (one frame of a batch of 8, or a band of rows), so that neighbouring
+    // workgroups -- which read the same cells -- share an L2.
+    const uint32_t L = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    if (L >= a.n_wg)
+        return;
+    const uint32_t per_frame = a.cbx_n * a.cby_n;
+    const uint32_t f = L / per_frame, rr = L - f * per_frame;
+    const int CBY = (int)(a.cby0 + rr / a.cbx_n), CBX = (int)(rr % a.cbx_n);
+    const uint32_t tf = f * a.t_stride;
+    const uint2 *BBf = a.BBp + (size_t)f * a.bb_stride;
+    const uint2 *SBf = a.SBp + (size_t)f * a.sb_stride;
+    const uint32_t pb = a.pos_bits, ring_shift = pb + 2u;
+
+    // ---- the lane's query ----
+    const uint32_t c = lane >> 2, m = lane & 3u;
+    const uint32_t cx = (uint32_t)CBX * 8u + (c & 7u), cy = (uint32_t)CBY * 8u + wv * 2u + (c >> 3);
+    const uint32_t x = 2u * cx - 1u + (m & 1u), y = 2u * cy - 1u + (m >> 1); // may wrap: invalid
+    const bool valid = x < a.w && y >= a.row0 && y < a.row1 && a.rp.owns(y);
+    LaneQ q;
+    q.qx = (int)cx;
+    q.qy = (int)cy;
+    q.lo = q.hi = 0u;
+    q.best = kTileNoKey;
+    q.limit = 0u;
+    uint32_t s_end = 0;
+    unsigned long long n_ring0 = 0, n_tests = 0, n_probed = 0, n_near = 0, n_survey = 0, n_super = 0;
+    if (valid) {
+        const uint8_t *p = a.main_px[f] + (size_t)y * a.mstride + (size_t)x * a.mch;
+        const uint8_t v[3] = {p[0], p[1], p[2]};
+        make_box(v, a.prec, q.lo, q.hi);
+        if (cx < a.wa && cy < a.ha && a.max_steps > 0) {
+            // ring 0: the centre cell (helpers.rs:26-35 with s = 0)
+            const uint32_t cell = a.T[tf + ((uint32_t)CBY * a.bw + (uint32_t)CBX) * 64u +
+                                      ((cy & 7u) << 3) + (cx & 7u)];
+            const uint32_t smax = max(max(cx, a.wa - 1u - cx), max(cy, a.ha - 1u - cy));
+            s_end = min(a.max_steps, smax + 1u); // rings 0..s_end-1 hold in-bounds cells
+            if (cell_in_box(cell, q.lo, q.hi))
+                q.best = 0u; // ring 0, distance 0
+            else if (s_end > 1u)
+                q.limit = s_end;
+            if constexpr (STATS)
+                n_ring0 = q.best == 0u;
+        }
+    }
+
+    if (__builtin_amdgcn_ballot_w64(q.limit != 0u)) {
+        // superblock window of the wave (far phase): every lane's window of radius
+        // max_steps-1 lies inside it
+        const int R = (int)a.max_steps - 1;
+        const int wx0 = CBX * 8, wy0 = CBY * 8 + (int)wv * 2;
+        const int sx0 = max(wx0 - R, 0) >> 6, sy0 = max(wy0 - R, 0) >> 6;
+        const int sx1 = min(wx0 + 7 + R, (int)a.wa - 1) >> 6, sy1 = min(wy0 + 1 + R, (int)a.ha - 1) >> 6;
+        const int nsx = sx1 - sx0 + 1, nsy = sy1 - sy0 + 1; // <= 10 each for max_steps <= 258
+        uint32_t skey0 = kTileNoKey, skey1 = kTileNoKey, skey2 = kTileNoKey; // slot ty*16+tx
+
+        for (uint32_t it = 0;; ++it) {
+            int bx0, by0, r_lo, r_hi;
+            uint64_t allow;
+            bool want;
+            if (it == 0) {
+                // step 0: block-rings 0..3 around the centre block
+                bx0 = CBX - 3;
+                by0 = CBY - 3;
+                allow = 0x007F7F7F7F7F7F7Full; // 7 rows x 7 columns
+                r_lo = 0;
+                r_hi = 3;
+                want = q.limit != 0u;
+                if constexpr (STATS)
+                    ++n_near;
+            } else {
+                if (it == 1) {
+                    // settled: best ring <= 24, or nothing beyond ring 24 to search
+                    if (q.limit != 0u &&
+                        (s_end <= 25u || (q.best != kTileNoKey && (q.best >> ring_shift) <= 24u)))
+                        q.limit = 0u;
+                    if (!__builtin_amdgcn_ballot_w64(q.limit != 0u))
+                        break;
+                    // survey: superblocks whose bounds meet some lane's box within its reach
+                    if constexpr (STATS)
+                        ++n_survey;
+                    for (int ty = 0; ty < nsy; ++ty) {
+                        const int sy = sy0 + ty;
+                        const uint2 *sbrow = SBf + (size_t)sy * a.sbwp + sx0;
+                        const int ay = (sy << 6) - q.qy;
+                        const int dsy = max(max(ay, -63 - ay), 0);
+                        for (int tx = 0; tx < nsx; ++tx) {
+                            const uint2 sb = sbrow[tx];
+                            const int ax = ((sx0 + tx) << 6) - q.qx;
+                            const uint32_t dS = (uint32_t)max(max(max(ax, -63 - ax), 0), dsy);
+                            const bool w = dS < q.limit && box_meets(sb.x, sb.y, q.lo, q.hi);
+                            if constexpr (STATS)
+                                n_tests += q.limit != 0u;
+                            if (__builtin_amdgcn_ballot_w64(w)) {
+                                // distance from the middle of the wave's centres orders the visits
+                                const int rx = ((sx0 + tx) << 6) - (wx0 + 4), ry = (sy << 6) - (wy0 + 1);
+                                const uint32_t dref = (uint32_t)max(max(max(rx, -63 - rx), max(ry, -63 - ry)), 0);
+                                const uint32_t t = (uint32_t)(ty * 16 + tx);
+                                const uint32_t key = (dref << 8) | t;
+                                if (lane == (t & 63u)) {
+                                    if (t < 64u)
+                                        skey0 = key;
+                                    else if (t < 128u)
+                                        skey1 = key;
+                                    else
+                                        skey2 = key;
+                                }
+                            }
+                        }
+                    }
+                }
+                // nearest superblock some lane may still want
+                const uint32_t pick = wave_min_dpp(min(min(skey0, skey1), skey2));
+                if (pick == kTileNoKey)
+                    break;
+                skey0 = skey0 == pick ? kTileNoKey : skey0;
+                skey1 = skey1 == pick ? kTileNoKey : skey1;
+                skey2 = skey2 == pick ? kTileNoKey : skey2;
+                const int sx = sx0 + (int)(pick & 15u), sy = sy0 + (int)((pick >> 4) & 15u);
+                const uint2 sb = SBf[(size_t)sy * a.sbwp + sx];
+                const int ax = (sx << 6) - q.qx, ay = (sy << 6) - q.qy;
+                const uint32_t dS = (uint32_t)max(max(max(ax, -63 - ax), max(ay, -63 - ay)), 0);
+                want = dS < q.limit && box_meets(sb.x, sb.y, q.lo, q.hi);
+                if (!__builtin_amdgcn_ballot_w64(want))
+                    continue;
+                bx0 = sx * 8;
+                by0 = sy * 8;
+                allow = ~window_le_mask(bx0, by0, CBX, CBY, 3); // step 0 did block-rings 0..3
+                window_ring_range(bx0, by0, CBX, CBY, r_lo, r_hi);
+                r_lo = max(r_lo, 4);
+                if constexpr (STATS)
+                    ++n_super;
+            }
+
+            // ---- bounds of the window's 8x8 blocks against the lane's box ----
+            uint32_t m_lo = 0, m_hi = 0; // bit row*8+col
+            {
+                const uint2 *win = BBf + (size_t)(by0 + kPadB) * a.bwp + (size_t)(bx0 + kPadB);
+#pragma unroll
+                for (int row = 7; row >= 4; --row) {
+                    const uint4 *rp4 = reinterpret_cast<const uint4 *>(win + (size_t)row * a.bwp);
+                    m_hi = test_row(m_hi, rp4[0], rp4[1], rp4[2], rp4[3], q.lo, q.hi);
+                }
+#pragma unroll
+                for (int row = 3; row >= 0; --row) {
+                    const uint4 *rp4 = reinterpret_cast<const uint4 *>(win + (size_t)row * a.bwp);
+                    m_lo = test_row(m_lo, rp4[0], rp4[1], rp4[2], rp4[3], q.lo, q.hi);
+                }
+            }
+            if constexpr (STATS)
+                n_tests += want ? 64u : 0u;
+            uint64_t cand = want ? (((uint64_t)m_hi << 32) | m_lo) & allow : 0ull;
+
+            // ---- probe the passing blocks, block-ring by block-ring (nearest first) ----
+            uint64_t le_prev = r_lo > 0 ? window_le_mask(bx0, by0, CBX, CBY, r_lo - 1) : 0ull;
+            for (int r = r_lo; r <= r_hi; ++r) {
+                const uint64_t le = window_le_mask(bx0, by0, CBX, CBY, r);
+                uint64_t cur = cand & le & ~le_prev;
+                le_prev = le;
+                // a block of block-ring r has no cell nearer than ring 8(r-1)+1
+                if (8 * (r - 1) + 1 >= (int)q.limit)
+                    cur = 0ull;
+                if (!__builtin_amdgcn_ballot_w64(cur != 0ull))
+                    continue;
+                while (cur != 0ull) {
+                    const int k = __builtin_ctzll(cur);
+                    cur &= cur - 1ull;
+                    const int bx = bx0 + (k & 7), by = by0 + (k >> 3);
+                    const int x0 = bx * 8 - q.qx, y0 = by * 8 - q.qy;
+                    // the dmin test also keeps stale bounds of rows this call did not pack
+                    // (they are out of every query's reach) from ever being probed
+                    if ((uint32_t)square_dmin(x0, y0, 8) < q.limit) {
+                        const uint32_t boff = tf + ((uint32_t)by * a.bw + (uint32_t)bx) * 64u;
+                        const uint32_t nl = probe_block(q, x0, y0, pb, a.T + boff, a.TT + boff);
+                        if constexpr (STATS) {
+                            ++n_probed;
+                            n_tests += 8u * nl;
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- distance, store, max (depth_image.rs:118-124) ----
+    uint32_t d8 = 0;
+    if (q.best != kTileNoKey && q.best != 0u)
+        d8 = key_distance(q.best, pb) & 0xffu; // `d as u8` wraps (depth_image.rs:121)
+    if (valid)
+        a.raw[(size_t)f * a.raw_stride + (size_t)(y - a.row0) * a.w + x] = (uint8_t)d8;
+    const uint32_t wmax = wave_max_u32(d8);
+    if (lane == 0)
+        s_max[wv] = wmax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t mx = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+        // most workgroups find nothing beyond what is already there: a plain read first keeps
+        // the same-address atomics (~11 ns each, chip-wide) off the common path
+        if (mx > __hip_atomic_load(a.max_word + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(a.max_word + f, mx);
+    }
+    if constexpr (STATS) {
+        // lane-level counts: ring-0 hits, bound tests + cells examined, blocks probed
+        unsigned long long v0 = n_ring0, v1 = n_tests, v5 = n_probed;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            v0 += __shfl_xor(v0, o, 64);
+            v1 += __shfl_xor(v1, o, 64);
+            v5 += __shfl_xor(v5, o, 64);
+        }
+        if (lane == 0) {
+            atomicAdd(&a.stats[0], v0);
+            atomicAdd(&a.stats[1], v1);
+            atomicAdd(&a.stats[2], n_near);
+            atomicAdd(&a.stats[3], n_survey);
+            atomicAdd(&a.stats[4], n_super);
+            atomicAdd(&a.stats[5], v5);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// pack for the dense search: RGB8 [Ha][Wa] -> T, TT (cells, row- and column-major inside
+// the 8x8 block) and the padded block bounds BBp.  One wave per block.  Replaces
+// disage::converters::raw_rgb + pixels_to_array (src/depth_image.rs:97-100).
+// ---------------------------------------------------------------------------------------
+struct TilePackArgs {
+    const uint8_t *src[kMaxBatch];
+    size_t stride;
+    uint32_t wa, ha, bw, bh, bwp;
+    uint32_t *T, *TT;
+    uint2 *BBp;
+    uint32_t by0, nby; // block rows to pack
+    uint32_t *zero;    // words cleared for the kernels that follow
+    uint32_t n_zero;
+    uint32_t t_stride, bb_stride;
+};
+
+__global__ __launch_bounds__(256) void tile_pack_kernel(TilePackArgs a)
+{
+    const uint32_t lane = threadIdx.x & 63u, f = blockIdx.y;
+    if (blockIdx.x == 0 && f == 0)
+        for (uint32_t i = threadIdx.x; i < a.n_zero; i += blockDim.x)
+            a.zero[i] = 0u;
+    const uint32_t idx = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (idx >= a.bw * a.nby)
+        return;
+    const uint32_t bx = idx % a.bw, by = a.by0 + idx / a.bw;
+    const uint32_t blk = by * a.bw + bx;
+    const uint32_t x = bx * kBlk + (lane & 7u), y = by * kBlk + (lane >> 3);
+    uint32_t cell = kNoCell;
+    uint32_t mn[3] = {255u, 255u, 255u}, mx[3] = {0u, 0u, 0u};
+    if (x < a.wa && y < a.ha) {
+        const uint8_t *p = a.src[f] + (size_t)y * a.stride + (size_t)x * 3;
+        mn[0] = mx[0] = p[0];
+        mn[1] = mx[1] = p[1];
+        mn[2] = mx[2] = p[2];
+        cell = pack_cell(p[0], p[1], p[2]);
+    }
+    const size_t base = (size_t)f * a.t_stride + (size_t)blk * 64u;
+    a.T[base + lane] = cell;
+    a.TT[base + ((lane & 7u) << 3) + (lane >> 3)] = cell;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        mn[c] = wave_min_u32(mn[c]);
+        mx[c] = wave_max_u32(mx[c]);
+    }
+    if (lane == 0)
+        a.BBp[(size_t)f * a.bb_stride + (size_t)(by + kPadB) * a.bwp + bx + kPadB] =
+            make_uint2(pack_cell(mx[0], mx[1], mx[2]), pack_cell(mn[0], mn[1], mn[2]));
+}
+
+// superblock bounds from the padded block bounds: one wave folds 8x8 blocks
+struct TileSuperArgs {
+    const uint2 *BBp;
+    uint32_t bw, bh, bwp, sbw, sbwp;
+    uint2 *SBp;
+    uint32_t sby0, nsby; // superblock rows to fold
+    uint32_t by0, by1;   // block rows that are valid (others hold stale bounds)
+    uint32_t bb_stride, sb_stride;
+};
+
+__global__ __launch_bounds__(256) void tile_super_kernel(TileSuperArgs a)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t idx = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (idx >= a.sbw * a.nsby)
+        return;
+    const uint32_t sx = idx % a.sbw, sy = a.sby0 + idx / a.sbw;
+    const uint32_t bx = sx * 8u + (lane & 7u), by = sy * 8u + (lane >> 3);
+    uint32_t mn[3] = {255u, 255u, 255u}, mx[3] = {0u, 0u, 0u};
+    bool any = false;
+    if (bx < a.bw && by >= a.by0 && by < a.by1) {
+        const uint2 bb = a.BBp[(size_t)blockIdx.y * a.bb_stride + (size_t)(by + kPadB) * a.bwp + bx + kPadB];
+        any = true;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            mx[c] = (bb.x >> (10 * c)) & 0xffu;
+            mn[c] = (bb.y >> (10 * c)) & 0xffu;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        mn[c] = wave_min_u32(mn[c]);
+        mx[c] = wave_max_u32(mx[c]);
+    }
+    const bool some = __builtin_amdgcn_ballot_w64(any) != 0ull;
+    if (lane == 0)
+        a.SBp[(size_t)blockIdx.y * a.sb_stride + (size_t)sy * a.sbwp + sx] =
+            some ? make_uint2(pack_cell(mx[0], mx[1], mx[2]), pack_cell(mn[0], mn[1], mn[2]))
+                 : make_uint2(0u, 0u); // nothing valid here: never matches
+}
+
+} // namespace stepth

@@ -1,0 +1,101 @@
+"""CPU check of the dense "lane = query" search (stepth_amd/csrc/tile_kernels.h).
+
+tests/tools/tile_emulate.cpp compiles the kernel's own per-lane headers (tile_lane.h,
+cell_pack.h) for the host and mirrors the wave-level control flow of ring_tile_kernel with
+plain loops; its raw distance map must equal the oracle's (the restatement of
+/root/reference/src/helpers.rs:9-54 + src/depth_image.rs:112-123) bit for bit.  The GPU suite
+(test_gpu_ring_parity.py) checks the kernel itself; this one pins the algorithm without a GPU.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+
+@pytest.fixture(scope="module")
+def emu(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("tile_emu") / "tile_emulate.so")
+    subprocess.run(["g++", "-O2", "-shared", "-fPIC", "-std=c++17",
+                    "-I", os.path.join(ROOT, "stepth_amd", "csrc"),
+                    os.path.join(ROOT, "tests", "tools", "tile_emulate.cpp"), "-o", out], check=True)
+    lib = C.CDLL(out)
+    lib.tile_emulate.restype = C.c_int
+    lib.tile_emulate.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32,
+                                 C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p,
+                                 C.c_void_p, C.c_void_p]
+
+    def run(main, add, prec, max_steps, rows=None):
+        main = np.ascontiguousarray(main)
+        add = np.ascontiguousarray(add[..., :3])
+        H, W, ch = main.shape
+        r0, r1 = rows if rows else (0, H)
+        raw = np.full((r1 - r0, W), 0xEE, np.uint8)
+        mx = C.c_uint32(0)
+        st = (C.c_uint64 * 3)()
+        pr = (C.c_uint8 * 3)(*prec)
+        rc = lib.tile_emulate(main.ctypes.data, W, H, ch, add.ctypes.data, add.shape[1], add.shape[0],
+                              C.cast(pr, C.c_void_p), max_steps, r0, r1, raw.ctypes.data,
+                              C.cast(C.byref(mx), C.c_void_p), C.cast(st, C.c_void_p))
+        assert rc == 0, f"tile_emulate failed with {rc}"
+        return raw, mx.value, list(st)
+    return run
+
+
+def _check(emu, oracle, main, add, prec, ms, rows=None):
+    ref = oracle.depth_from_additional(main[..., :3], add, prec, ms, (1, 1))
+    raw, mx, _ = emu(main, add, prec, ms, rows)
+    want = ref["raw"] if rows is None else ref["raw"][rows[0]:rows[1]]
+    bad = np.argwhere(raw != want)
+    assert len(bad) == 0, f"{len(bad)} pixels differ, first at {bad[0]}: {raw[tuple(bad[0])]} vs {want[tuple(bad[0])]}"
+    if rows is None:
+        assert mx == ref["max"]
+
+
+def test_asset_pair(emu, oracle, asset):
+    _check(emu, oracle, asset["main"], asset["additional"], [36] * 3, 255)
+
+
+@pytest.mark.parametrize("w,h,ms,prec,seed", [
+    (200, 120, 255, 36, 1), (203, 117, 64, 36, 2), (96, 64, 255, 6, 3), (160, 96, 9, 36, 4),
+    (320, 180, 128, 36, 5), (64, 40, 2, 36, 6), (130, 70, 26, 20, 7), (17, 9, 255, 36, 8),
+])
+def test_synthetic_pairs(emu, oracle, w, h, ms, prec, seed):
+    from stepth_amd import synth
+    l, r, _ = synth.stereo_pair(w, h, min(ms, 64), seed=seed)
+    _check(emu, oracle, l, r, [prec] * 3, ms)
+
+
+def test_long_reach_sparse_matches(emu, oracle):
+    """few matching cells, far away: the superblock phase, rings up to 254, `d as u8` wraps"""
+    rng = np.random.default_rng(11)
+    main = np.full((300, 520, 3), 200, np.uint8)
+    add = rng.integers(0, 60, (300, 520, 3), dtype=np.uint8)
+    ys, xs = rng.integers(0, 300, 40), rng.integers(0, 520, 40)
+    add[ys, xs] = 200
+    _check(emu, oracle, main, add, [36] * 3, 255)
+    _check(emu, oracle, main, add, [36] * 3, 100)
+
+
+def test_unequal_sizes_rgba_and_strips(emu, oracle):
+    rng = np.random.default_rng(5)
+    main = rng.integers(0, 256, (90, 150, 4), dtype=np.uint8)
+    main[..., :3] //= 3
+    add = (rng.integers(0, 256, (37, 61, 3), dtype=np.uint8) // 3).astype(np.uint8)
+    _check(emu, oracle, main, add, [30] * 3, 255)  # centres beyond the small array: None -> 0
+    _check(emu, oracle, main, add, [30] * 3, 255, rows=(30, 61))
+    _check(emu, oracle, main, add, [30, 0, 30], 255)  # precision 0 on a channel: nothing matches
+    _check(emu, oracle, main, add, [255] * 3, 255)  # everything matches (empty borders must not)
+
+
+def test_scan_order_ties(emu, oracle):
+    """blocky images make many equal-ring candidates: side and position order decide"""
+    rng = np.random.default_rng(9)
+    coarse = rng.integers(0, 4, (12, 20, 3), dtype=np.uint8) * 70
+    add = np.repeat(np.repeat(coarse, 9, axis=0), 9, axis=1)[:100, :170]
+    main = np.repeat(np.repeat(rng.integers(0, 4, (24, 40, 3), dtype=np.uint8) * 70, 9, axis=0), 9, axis=1)[:200, :340]
+    _check(emu, oracle, main, add, [36] * 3, 255)
+    _check(emu, oracle, main, add, [36] * 3, 40)

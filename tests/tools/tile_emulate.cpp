@@ -1,0 +1,247 @@
+// tile_emulate.cpp -- CPU emulation of ring_tile_kernel (stepth_amd/csrc/tile_kernels.h).
+//
+// Test infrastructure: runs the kernel's per-lane code (tile_lane.h, cell_pack.h -- the very
+// same headers) and mirrors its wave-level control flow with plain loops over 64 "lanes", so
+// that the logic of the dense search can be checked against the oracle without a GPU
+// (tests/test_tile_emulation.py).  Nothing in the product uses this file.
+//
+// build: g++ -O2 -shared -fPIC -I stepth_amd/csrc tests/tools/tile_emulate.cpp -o <out>.so
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "tile_lane.h"
+
+using namespace stepth;
+
+namespace {
+constexpr int kPadB = 4;
+uint32_t tile_bwp(uint32_t bw) { return ((bw + 7u) & ~7u) + 8u; }
+uint32_t tile_bhp(uint32_t bh) { return ((bh + 7u) & ~7u) + 8u; }
+struct U2 {
+    uint32_t x, y;
+};
+} // namespace
+
+extern "C" int tile_emulate(const uint8_t *main_px, uint32_t W, uint32_t H, uint32_t mch,
+                            const uint8_t *add, uint32_t wa, uint32_t ha, const uint8_t *prec,
+                            uint32_t max_steps_in, uint32_t row0, uint32_t row1, uint8_t *raw,
+                            uint32_t *max_out, uint64_t *stats /* [3]: probes, lines, steps */)
+{
+    const uint32_t bw = (wa + 7) / 8, bh = (ha + 7) / 8, sbw = (bw + 7) / 8, sbh = (bh + 7) / 8;
+    const uint32_t bwp = tile_bwp(bw), bhp = tile_bhp(bh);
+    std::vector<uint32_t> T((size_t)bw * bh * 64, kNoCell), TT((size_t)bw * bh * 64, kNoCell);
+    std::vector<U2> BBp((size_t)bwp * bhp, U2{0, 0}), SB((size_t)sbw * sbh, U2{0, 0});
+    // pack (tile_pack_kernel / tile_super_kernel)
+    for (uint32_t by = 0; by < bh; ++by)
+        for (uint32_t bx = 0; bx < bw; ++bx) {
+            uint32_t mn[3] = {255, 255, 255}, mx[3] = {0, 0, 0};
+            for (uint32_t l = 0; l < 64; ++l) {
+                const uint32_t x = bx * 8 + (l & 7), y = by * 8 + (l >> 3);
+                uint32_t cell = kNoCell;
+                if (x < wa && y < ha) {
+                    const uint8_t *p = add + ((size_t)y * wa + x) * 3;
+                    for (int c = 0; c < 3; ++c) {
+                        mn[c] = std::min<uint32_t>(mn[c], p[c]);
+                        mx[c] = std::max<uint32_t>(mx[c], p[c]);
+                    }
+                    cell = pack_cell(p[0], p[1], p[2]);
+                }
+                const size_t base = ((size_t)by * bw + bx) * 64;
+                T[base + l] = cell;
+                TT[base + ((l & 7) << 3) + (l >> 3)] = cell;
+            }
+            BBp[(size_t)(by + kPadB) * bwp + bx + kPadB] =
+                U2{pack_cell(mx[0], mx[1], mx[2]), pack_cell(mn[0], mn[1], mn[2])};
+        }
+    for (uint32_t sy = 0; sy < sbh; ++sy)
+        for (uint32_t sx = 0; sx < sbw; ++sx) {
+            uint32_t mn[3] = {255, 255, 255}, mx[3] = {0, 0, 0};
+            for (uint32_t l = 0; l < 64; ++l) {
+                const uint32_t bx = sx * 8 + (l & 7), by = sy * 8 + (l >> 3);
+                if (bx >= bw || by >= bh)
+                    continue;
+                const U2 bb = BBp[(size_t)(by + kPadB) * bwp + bx + kPadB];
+                for (int c = 0; c < 3; ++c) {
+                    mx[c] = std::max(mx[c], (bb.x >> (10 * c)) & 0xffu);
+                    mn[c] = std::min(mn[c], (bb.y >> (10 * c)) & 0xffu);
+                }
+            }
+            SB[(size_t)sy * sbw + sx] = U2{pack_cell(mx[0], mx[1], mx[2]), pack_cell(mn[0], mn[1], mn[2])};
+        }
+
+    const uint32_t max_steps = std::min(max_steps_in, std::max(wa, ha));
+    const uint32_t top = std::max(max_steps, 2u) - 1u;
+    uint32_t pb = 1;
+    while ((2u * top) >> pb)
+        ++pb;
+    const uint32_t ring_shift = pb + 2;
+    const uint32_t cbx_n = ((W >> 1) + 8u) >> 3, cby0 = ((row0 + 1u) >> 1) >> 3;
+    const uint32_t cby_n = ((row1 >> 1) >> 3) - cby0 + 1u;
+    uint32_t mxd = 0;
+    uint64_t n_probes = 0, n_lines = 0, n_steps = 0;
+
+    for (uint32_t cbyi = 0; cbyi < cby_n; ++cbyi)
+        for (uint32_t cbxi = 0; cbxi < cbx_n; ++cbxi)
+            for (uint32_t wv = 0; wv < 4; ++wv) {
+                const int CBX = (int)cbxi, CBY = (int)(cby0 + cbyi);
+                LaneQ q[64];
+                uint32_t s_end[64], px[64], py[64];
+                bool valid[64];
+                bool any = false;
+                for (uint32_t lane = 0; lane < 64; ++lane) {
+                    const uint32_t c = lane >> 2, m = lane & 3;
+                    const uint32_t cx = CBX * 8u + (c & 7), cy = CBY * 8u + wv * 2 + (c >> 3);
+                    const uint32_t x = 2 * cx - 1 + (m & 1), y = 2 * cy - 1 + (m >> 1);
+                    valid[lane] = x < W && y >= row0 && y < row1;
+                    px[lane] = x;
+                    py[lane] = y;
+                    LaneQ &l = q[lane];
+                    l.qx = (int)cx;
+                    l.qy = (int)cy;
+                    l.lo = l.hi = 0;
+                    l.best = kTileNoKey;
+                    l.limit = 0;
+                    s_end[lane] = 0;
+                    if (!valid[lane])
+                        continue;
+                    const uint8_t *p = main_px + ((size_t)y * W + x) * mch;
+                    const uint8_t v[3] = {p[0], p[1], p[2]};
+                    make_box(v, prec, l.lo, l.hi);
+                    if (cx < wa && cy < ha && max_steps > 0) {
+                        const uint32_t cell = T[((size_t)CBY * bw + CBX) * 64 + ((cy & 7) << 3) + (cx & 7)];
+                        const uint32_t smax = std::max(std::max(cx, wa - 1 - cx), std::max(cy, ha - 1 - cy));
+                        s_end[lane] = std::min(max_steps, smax + 1);
+                        if (cell_in_box(cell, l.lo, l.hi))
+                            l.best = 0;
+                        else if (s_end[lane] > 1)
+                            l.limit = s_end[lane];
+                    }
+                    any |= l.limit != 0;
+                }
+                if (any) {
+                    const int R = (int)max_steps - 1;
+                    const int wx0 = CBX * 8, wy0 = CBY * 8 + (int)wv * 2;
+                    const int sx0 = std::max(wx0 - R, 0) >> 6, sy0 = std::max(wy0 - R, 0) >> 6;
+                    const int sx1 = std::min(wx0 + 7 + R, (int)wa - 1) >> 6;
+                    const int sy1 = std::min(wy0 + 1 + R, (int)ha - 1) >> 6;
+                    const int nsx = sx1 - sx0 + 1, nsy = sy1 - sy0 + 1;
+                    if (nsx > 16 || nsy > 12)
+                        return -1; // the kernel's slots would not fit
+                    std::vector<uint32_t> skeys; // wave-level slots
+                    for (uint32_t it = 0;; ++it) {
+                        int bx0, by0, r_lo, r_hi;
+                        uint64_t allow;
+                        bool want[64];
+                        if (it == 0) {
+                            bx0 = CBX - 3;
+                            by0 = CBY - 3;
+                            allow = 0x007F7F7F7F7F7F7Full;
+                            r_lo = 0;
+                            r_hi = 3;
+                            for (int l = 0; l < 64; ++l)
+                                want[l] = q[l].limit != 0;
+                        } else {
+                            if (it == 1) {
+                                bool left = false;
+                                for (int l = 0; l < 64; ++l) {
+                                    if (q[l].limit != 0 &&
+                                        (s_end[l] <= 25 || (q[l].best != kTileNoKey && (q[l].best >> ring_shift) <= 24)))
+                                        q[l].limit = 0;
+                                    left |= q[l].limit != 0;
+                                }
+                                if (!left)
+                                    break;
+                                for (int ty = 0; ty < nsy; ++ty)
+                                    for (int tx = 0; tx < nsx; ++tx) {
+                                        const int sx = sx0 + tx, sy = sy0 + ty;
+                                        const U2 sb = SB[(size_t)sy * sbw + sx];
+                                        bool anyw = false;
+                                        for (int l = 0; l < 64; ++l) {
+                                            const uint32_t dS = (uint32_t)square_dmin((sx << 6) - q[l].qx, (sy << 6) - q[l].qy, 64);
+                                            anyw |= dS < q[l].limit && box_meets(sb.x, sb.y, q[l].lo, q[l].hi);
+                                        }
+                                        if (anyw) {
+                                            const uint32_t dref = (uint32_t)square_dmin((sx << 6) - (wx0 + 4), (sy << 6) - (wy0 + 1), 64);
+                                            skeys.push_back((dref << 8) | (uint32_t)(ty * 16 + tx));
+                                        }
+                                    }
+                            }
+                            if (skeys.empty())
+                                break;
+                            const auto itmin = std::min_element(skeys.begin(), skeys.end());
+                            const uint32_t pick = *itmin;
+                            skeys.erase(itmin);
+                            const int sx = sx0 + (int)(pick & 15u), sy = sy0 + (int)((pick >> 4) & 15u);
+                            const U2 sb = SB[(size_t)sy * sbw + sx];
+                            bool anyw = false;
+                            for (int l = 0; l < 64; ++l) {
+                                const uint32_t dS = (uint32_t)square_dmin((sx << 6) - q[l].qx, (sy << 6) - q[l].qy, 64);
+                                want[l] = dS < q[l].limit && box_meets(sb.x, sb.y, q[l].lo, q[l].hi);
+                                anyw |= want[l];
+                            }
+                            if (!anyw)
+                                continue;
+                            bx0 = sx * 8;
+                            by0 = sy * 8;
+                            allow = ~window_le_mask(bx0, by0, CBX, CBY, 3);
+                            window_ring_range(bx0, by0, CBX, CBY, r_lo, r_hi);
+                            r_lo = std::max(r_lo, 4);
+                        }
+                        ++n_steps;
+                        uint64_t cand[64];
+                        for (int l = 0; l < 64; ++l) {
+                            uint64_t mm = 0;
+                            for (int row = 0; row < 8; ++row)
+                                for (int col = 0; col < 8; ++col) {
+                                    const U2 bb = BBp[(size_t)(by0 + kPadB + row) * bwp + (size_t)(bx0 + kPadB + col)];
+                                    if (box_meets(bb.x, bb.y, q[l].lo, q[l].hi))
+                                        mm |= 1ull << (row * 8 + col);
+                                }
+                            cand[l] = want[l] ? mm & allow : 0ull;
+                        }
+                        uint64_t le_prev = r_lo > 0 ? window_le_mask(bx0, by0, CBX, CBY, r_lo - 1) : 0ull;
+                        for (int r = r_lo; r <= r_hi; ++r) {
+                            const uint64_t le = window_le_mask(bx0, by0, CBX, CBY, r);
+                            for (int l = 0; l < 64; ++l) {
+                                uint64_t cur = cand[l] & le & ~le_prev;
+                                if (8 * (r - 1) + 1 >= (int)q[l].limit)
+                                    cur = 0;
+                                while (cur) {
+                                    const int k = __builtin_ctzll(cur);
+                                    cur &= cur - 1;
+                                    const int bx = bx0 + (k & 7), by = by0 + (k >> 3);
+                                    const int x0 = bx * 8 - q[l].qx, y0 = by * 8 - q[l].qy;
+                                    if ((uint32_t)square_dmin(x0, y0, 8) < q[l].limit) {
+                                        if (bx < 0 || by < 0 || bx >= (int)bw || by >= (int)bh)
+                                            return -2; // a padded block got through: memory fault on the GPU
+                                        const size_t boff = ((size_t)by * bw + bx) * 64;
+                                        n_lines += probe_block(q[l], x0, y0, pb, &T[boff], &TT[boff]);
+                                        ++n_probes;
+                                    }
+                                }
+                            }
+                            le_prev = le;
+                        }
+                    }
+                }
+                for (int l = 0; l < 64; ++l) {
+                    uint32_t d8 = 0;
+                    if (q[l].best != kTileNoKey && q[l].best != 0)
+                        d8 = key_distance(q[l].best, pb) & 0xff;
+                    if (valid[l]) {
+                        raw[(size_t)(py[l] - row0) * W + px[l]] = (uint8_t)d8;
+                        mxd = std::max(mxd, d8);
+                    }
+                }
+            }
+    if (max_out)
+        *max_out = mxd;
+    if (stats) {
+        stats[0] = n_probes;
+        stats[1] = n_lines;
+        stats[2] = n_steps;
+    }
+    return 0;
+}
