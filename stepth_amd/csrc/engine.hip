@@ -52,7 +52,7 @@ struct stepth_engine {
     std::string err;
 
     DevBuf T, BB, SB;      // packed additional image: tiled cells, block / superblock bounds
-    DevBuf TT, BBp, SBp;   // dense search (tile_kernels.h): column-major cells, padded bounds
+    DevBuf TT, LB, BBp, SBp; // dense search (tile_kernels.h): column-major cells, line bounds, padded bounds
     uint32_t bbp_layout[3] = {0, 0, 0}; // bw, bh, frames the zero border of BBp was laid out for
     DevBuf stage_main, stage_add, stage_out, stage_groups;
     DevBuf queries, raw, aux32, aux_pos, aux_found, pending, pending_rec, pending_key;
@@ -262,6 +262,7 @@ int pack_additional_tiles(stepth_engine *e, uint32_t n_frames, const uint8_t *co
     const size_t bb_frame = (size_t)bwp * bhp, sb_frame = (size_t)sbwp * sbh;
     TRY(reserve(e, e->T, nblk * 64 * 4 * n_frames));
     TRY(reserve(e, e->TT, nblk * 64 * 4 * n_frames));
+    TRY(reserve(e, e->LB, nblk * 16 * 8 * n_frames));
     const size_t bbp_cap = e->BBp.cap;
     TRY(reserve(e, e->BBp, bb_frame * 8 * n_frames));
     TRY(reserve(e, e->SBp, sb_frame * 8 * n_frames));
@@ -289,6 +290,7 @@ int pack_additional_tiles(stepth_engine *e, uint32_t n_frames, const uint8_t *co
     pa.bwp = bwp;
     pa.T = (uint32_t *)e->T.p;
     pa.TT = (uint32_t *)e->TT.p;
+    pa.LB = (uint2 *)e->LB.p;
     pa.BBp = (uint2 *)e->BBp.p;
     pa.by0 = by0;
     pa.nby = by1 - by0;
@@ -328,6 +330,7 @@ int launch_tile(stepth_engine *e, const RingArgs &ra, uint32_t n_frames)
     TileArgs ta{};
     ta.T = (const uint32_t *)e->T.p;
     ta.TT = (const uint32_t *)e->TT.p;
+    ta.LB = (const uint2 *)e->LB.p;
     ta.BBp = (const uint2 *)e->BBp.p;
     ta.SBp = (const uint2 *)e->SBp.p;
     ta.wa = ra.wa;
@@ -683,7 +686,7 @@ void stepth_engine_destroy(stepth_engine *e)
         return;
     (void)hipSetDevice(e->device);
     (void)hipStreamSynchronize(e->stream);
-    for (DevBuf *b : {&e->T, &e->BB, &e->SB, &e->TT, &e->BBp, &e->SBp, &e->spiral, &e->stage_main, &e->stage_add, &e->stage_out,
+    for (DevBuf *b : {&e->T, &e->BB, &e->SB, &e->TT, &e->LB, &e->BBp, &e->SBp, &e->spiral, &e->stage_main, &e->stage_add, &e->stage_out,
                       &e->stage_groups, &e->queries, &e->raw, &e->aux32, &e->aux_pos,
                       &e->aux_found, &e->pending, &e->pending_rec, &e->pending_key, &e->sad_left, &e->sad_right, &e->gauss_tmp, &e->gauss_io,
                       &e->zone_counts, &e->zone_tables, &e->pipe_main[0], &e->pipe_main[1],

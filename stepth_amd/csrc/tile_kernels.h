@@ -51,6 +51,7 @@ STEPTH_HD uint32_t tile_sbwp(uint32_t sbw) { return sbw + 16u; } // rows are rea
 
 struct TileArgs {
     const uint32_t *T, *TT; // cells, 8x8 blocks: row-major / column-major inside a block
+    const uint2 *LB;        // per block: {max,min} of its 8 rows, then of its 8 columns
     const uint2 *BBp;       // block bounds {max,min}, [bhp][bwp], image block (0,0) at (kPadB,kPadB)
     const uint2 *SBp;       // superblock bounds, [sbh][sbwp]
     uint32_t wa, ha, bw, bh, bwp, sbwp;
@@ -73,26 +74,54 @@ __device__ __forceinline__ uint32_t rfl(uint32_t v)
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
 }
 
-// eight block-bound tests of one row, columns 7..0, shifted into `acc` (bit = column)
-__device__ __forceinline__ uint32_t test_row(uint32_t acc, const uint4 &v0, const uint4 &v1,
-                                             const uint4 &v2, const uint4 &v3, uint32_t lo,
-                                             uint32_t hi)
+// Four block-bound tests (one half of a row of 8 blocks), highest column first, shifted into
+// `acc` (bit = column): per block  t = max - lo, u = hi - min, r = (t & u) | ~guard,
+// vcc = (r == ~0), acc = acc + acc + vcc  -- five VALU instructions, the bounds straight from
+// the scalar registers the s_load left them in.  (b0x, b0y) = {max, min} of the lowest column.
+__device__ __forceinline__ uint32_t test_half_row(uint32_t acc, uint32_t b0x, uint32_t b0y,
+                                                  uint32_t b1x, uint32_t b1y, uint32_t b2x,
+                                                  uint32_t b2y, uint32_t b3x, uint32_t b3y,
+                                                  uint32_t lo, uint32_t hi)
 {
-    acc = acc + acc + (box_meets(v3.z, v3.w, lo, hi) ? 1u : 0u);
-    acc = acc + acc + (box_meets(v3.x, v3.y, lo, hi) ? 1u : 0u);
-    acc = acc + acc + (box_meets(v2.z, v2.w, lo, hi) ? 1u : 0u);
-    acc = acc + acc + (box_meets(v2.x, v2.y, lo, hi) ? 1u : 0u);
-    acc = acc + acc + (box_meets(v1.z, v1.w, lo, hi) ? 1u : 0u);
-    acc = acc + acc + (box_meets(v1.x, v1.y, lo, hi) ? 1u : 0u);
-    acc = acc + acc + (box_meets(v0.z, v0.w, lo, hi) ? 1u : 0u);
-    acc = acc + acc + (box_meets(v0.x, v0.y, lo, hi) ? 1u : 0u);
+    uint32_t t, u;
+    const uint32_t ng = ~kGuard;
+#define STEPTH_BT(MX, MN)                                                                      \
+    "v_sub_u32 %1, " MX ", %3\n v_subrev_u32 %2, " MN ", %4\n v_and_or_b32 %1, %1, %2, %5\n"    \
+    "v_cmp_eq_u32 vcc, -1, %1\n v_addc_co_u32 %0, vcc, %0, %0, vcc\n"
+    asm volatile(STEPTH_BT("%12", "%13") STEPTH_BT("%10", "%11") STEPTH_BT("%8", "%9")
+                     STEPTH_BT("%6", "%7")
+                 : "+v"(acc), "=&v"(t), "=&v"(u)
+                 : "v"(lo), "v"(hi), "s"(ng), "s"(b0x), "s"(b0y), "s"(b1x), "s"(b1y), "s"(b2x),
+                   "s"(b2y), "s"(b3x), "s"(b3y)
+                 : "vcc");
+#undef STEPTH_BT
     return acc;
 }
+
+// wave-wide unsigned max in 4 DPP steps + 4 readlanes (see wave_min_dpp)
+__device__ __forceinline__ uint32_t wave_max_dpp(uint32_t v)
+{
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x124, 0xF, 0xF, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x128, 0xF, 0xF, false));
+    return max(max(bcast(v, 0), bcast(v, 16)), max(bcast(v, 32), bcast(v, 48)));
+}
+
+// STEPTH_TILE_PROFILE (a tuning build, never the shipped one): the STATS variant reports
+// s_memtime ticks per phase in place of the step counts -- [2] bound tests, [3] survey,
+// [4] probes, [5] whole wave.
+#ifdef STEPTH_TILE_PROFILE
+#define STEPTH_TICK() (STATS ? __builtin_amdgcn_s_memtime() : 0ull)
+#else
+#define STEPTH_TICK() 0ull
+#endif
 
 template <bool STATS>
 __global__ __launch_bounds__(256) void ring_tile_kernel(TileArgs a)
 {
-    __shared__ uint32_t s_max[4];
+    [[maybe_unused]] unsigned long long pc_tests = 0, pc_survey = 0, pc_probe = 0;
+    [[maybe_unused]] const unsigned long long pc_t0 = STEPTH_TICK();
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wv = rfl(threadIdx.x >> 6);
     // Workgroup ids go round-robin over the 8 XCDs; give every XCD one contiguous range of
@@ -141,6 +170,9 @@ __global__ __launch_bounds__(256) void ring_tile_kernel(TileArgs a)
         }
     }
 
+#if defined(STEPTH_ABLATE) && STEPTH_ABLATE == 3 // tuning build: ring 0 only
+    q.limit = 0u;
+#endif
     if (__builtin_amdgcn_ballot_w64(q.limit != 0u)) {
         // superblock window of the wave (far phase): every lane's window of radius
         // max_steps-1 lies inside it
@@ -166,6 +198,9 @@ __global__ __launch_bounds__(256) void ring_tile_kernel(TileArgs a)
                 if constexpr (STATS)
                     ++n_near;
             } else {
+#if defined(STEPTH_ABLATE) && STEPTH_ABLATE == 1 // tuning build: step 0 only
+                break;
+#endif
                 if (it == 1) {
                     // settled: best ring <= 24, or nothing beyond ring 24 to search
                     if (q.limit != 0u &&
@@ -176,6 +211,7 @@ __global__ __launch_bounds__(256) void ring_tile_kernel(TileArgs a)
                     // survey: superblocks whose bounds meet some lane's box within its reach
                     if constexpr (STATS)
                         ++n_survey;
+                    [[maybe_unused]] const unsigned long long pc_s0 = STEPTH_TICK();
                     for (int ty = 0; ty < nsy; ++ty) {
                         const int sy = sy0 + ty;
                         const uint2 *sbrow = SBf + (size_t)sy * a.sbwp + sx0;
@@ -205,6 +241,7 @@ __global__ __launch_bounds__(256) void ring_tile_kernel(TileArgs a)
                             }
                         }
                     }
+                    pc_survey += STEPTH_TICK() - pc_s0;
                 }
                 // nearest superblock some lane may still want
                 const uint32_t pick = wave_min_dpp(min(min(skey0, skey1), skey2));
@@ -230,23 +267,47 @@ __global__ __launch_bounds__(256) void ring_tile_kernel(TileArgs a)
             }
 
             // ---- bounds of the window's 8x8 blocks against the lane's box ----
+            // Rows and half rows of blocks that lie beyond every lane's limit are skipped
+            // (wave-uniform: distances from the wave's 8x2 centres).
             uint32_t m_lo = 0, m_hi = 0; // bit row*8+col
+            [[maybe_unused]] const unsigned long long pc_b0 = STEPTH_TICK();
             {
+                const uint32_t wlim = wave_max_dpp(want ? q.limit : 0u);
+                const int cx_l = bx0 * 8 - (wx0 + 7), cx_r = wx0 - (bx0 * 8 + 31); // cols 0..3
+                const bool need_l = max(max(cx_l, cx_r), 0) < (int)wlim;
+                const bool need_h = max(max(cx_l + 32, cx_r - 32), 0) < (int)wlim;   // cols 4..7
                 const uint2 *win = BBf + (size_t)(by0 + kPadB) * a.bwp + (size_t)(bx0 + kPadB);
-#pragma unroll
-                for (int row = 7; row >= 4; --row) {
+                auto do_row = [&](uint32_t acc, int row) -> uint32_t {
+                    const int ry0 = (by0 + row) * 8 - (wy0 + 1), ry1 = wy0 - ((by0 + row) * 8 + 7);
+                    if (max(max(ry0, ry1), 0) >= (int)wlim || (it == 0 && row == 7))
+                        return acc << 8;
                     const uint4 *rp4 = reinterpret_cast<const uint4 *>(win + (size_t)row * a.bwp);
-                    m_hi = test_row(m_hi, rp4[0], rp4[1], rp4[2], rp4[3], q.lo, q.hi);
-                }
+                    if (need_h) {
+                        const uint4 v2 = rp4[2], v3 = rp4[3];
+                        acc = test_half_row(acc, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w, q.lo, q.hi);
+                    } else {
+                        acc <<= 4;
+                    }
+                    if (need_l) {
+                        const uint4 v0 = rp4[0], v1 = rp4[1];
+                        acc = test_half_row(acc, v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, q.lo, q.hi);
+                    } else {
+                        acc <<= 4;
+                    }
+                    return acc;
+                };
 #pragma unroll
-                for (int row = 3; row >= 0; --row) {
-                    const uint4 *rp4 = reinterpret_cast<const uint4 *>(win + (size_t)row * a.bwp);
-                    m_lo = test_row(m_lo, rp4[0], rp4[1], rp4[2], rp4[3], q.lo, q.hi);
-                }
+                for (int row = 7; row >= 4; --row)
+                    m_hi = do_row(m_hi, row);
+#pragma unroll
+                for (int row = 3; row >= 0; --row)
+                    m_lo = do_row(m_lo, row);
             }
             if constexpr (STATS)
                 n_tests += want ? 64u : 0u;
             uint64_t cand = want ? (((uint64_t)m_hi << 32) | m_lo) & allow : 0ull;
+            [[maybe_unused]] const unsigned long long pc_p0 = STEPTH_TICK();
+            pc_tests += pc_p0 - pc_b0;
 
             // ---- probe the passing blocks, block-ring by block-ring (nearest first) ----
             uint64_t le_prev = r_lo > 0 ? window_le_mask(bx0, by0, CBX, CBY, r_lo - 1) : 0ull;
@@ -266,9 +327,15 @@ __global__ __launch_bounds__(256) void ring_tile_kernel(TileArgs a)
                     const int x0 = bx * 8 - q.qx, y0 = by * 8 - q.qy;
                     // the dmin test also keeps stale bounds of rows this call did not pack
                     // (they are out of every query's reach) from ever being probed
+#if defined(STEPTH_ABLATE) && STEPTH_ABLATE == 2 // tuning build: no probes
+                    if (false) {
+#else
                     if ((uint32_t)square_dmin(x0, y0, 8) < q.limit) {
+#endif
                         const uint32_t boff = tf + ((uint32_t)by * a.bw + (uint32_t)bx) * 64u;
-                        const uint32_t nl = probe_block(q, x0, y0, pb, a.T + boff, a.TT + boff);
+                        const uint32_t nl =
+                            probe_block(q, x0, y0, pb, a.T + boff, a.TT + boff,
+                                        reinterpret_cast<const uint32_t *>(a.LB) + (boff >> 1));
                         if constexpr (STATS) {
                             ++n_probed;
                             n_tests += 8u * nl;
@@ -276,6 +343,7 @@ __global__ __launch_bounds__(256) void ring_tile_kernel(TileArgs a)
                     }
                 }
             }
+            pc_probe += STEPTH_TICK() - pc_p0;
         }
     }
 
@@ -285,17 +353,12 @@ __global__ __launch_bounds__(256) void ring_tile_kernel(TileArgs a)
         d8 = key_distance(q.best, pb) & 0xffu; // `d as u8` wraps (depth_image.rs:121)
     if (valid)
         a.raw[(size_t)f * a.raw_stride + (size_t)(y - a.row0) * a.w + x] = (uint8_t)d8;
-    const uint32_t wmax = wave_max_u32(d8);
-    if (lane == 0)
-        s_max[wv] = wmax;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const uint32_t mx = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
-        // most workgroups find nothing beyond what is already there: a plain read first keeps
-        // the same-address atomics (~11 ns each, chip-wide) off the common path
-        if (mx > __hip_atomic_load(a.max_word + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-            atomicMax(a.max_word + f, mx);
-    }
+    // Most waves find nothing beyond what is already there: a plain read first keeps the
+    // same-address atomics (~11 ns each, chip-wide) off the common path.  No workgroup
+    // barrier: a wave that is done leaves, whatever its neighbours still have to search.
+    const uint32_t wmax = wave_max_dpp(d8);
+    if (lane == 0 && wmax > __hip_atomic_load(a.max_word + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        atomicMax(a.max_word + f, wmax);
     if constexpr (STATS) {
         // lane-level counts: ring-0 hits, bound tests + cells examined, blocks probed
         unsigned long long v0 = n_ring0, v1 = n_tests, v5 = n_probed;
@@ -308,10 +371,17 @@ __global__ __launch_bounds__(256) void ring_tile_kernel(TileArgs a)
         if (lane == 0) {
             atomicAdd(&a.stats[0], v0);
             atomicAdd(&a.stats[1], v1);
+#ifdef STEPTH_TILE_PROFILE
+            atomicAdd(&a.stats[2], pc_tests);
+            atomicAdd(&a.stats[3], pc_survey);
+            atomicAdd(&a.stats[4], pc_probe);
+            atomicAdd(&a.stats[5], STEPTH_TICK() - pc_t0);
+#else
             atomicAdd(&a.stats[2], n_near);
             atomicAdd(&a.stats[3], n_survey);
             atomicAdd(&a.stats[4], n_super);
             atomicAdd(&a.stats[5], v5);
+#endif
         }
     }
 }
@@ -326,7 +396,7 @@ struct TilePackArgs {
     size_t stride;
     uint32_t wa, ha, bw, bh, bwp;
     uint32_t *T, *TT;
-    uint2 *BBp;
+    uint2 *LB, *BBp;
     uint32_t by0, nby; // block rows to pack
     uint32_t *zero;    // words cleared for the kernels that follow
     uint32_t n_zero;
@@ -357,6 +427,32 @@ __global__ __launch_bounds__(256) void tile_pack_kernel(TilePackArgs a)
     const size_t base = (size_t)f * a.t_stride + (size_t)blk * 64u;
     a.T[base + lane] = cell;
     a.TT[base + ((lane & 7u) << 3) + (lane >> 3)] = cell;
+    // line bounds: rows = the 8 lanes with the same lane >> 3, columns = same lane & 7
+    {
+        uint32_t rn[3], rx[3], cn[3], cm[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            rn[c] = cn[c] = mn[c];
+            rx[c] = cm[c] = mx[c];
+#pragma unroll
+            for (int o = 1; o < 8; o <<= 1) {
+                rn[c] = min(rn[c], (uint32_t)__shfl_xor((int)rn[c], o, 64));
+                rx[c] = max(rx[c], (uint32_t)__shfl_xor((int)rx[c], o, 64));
+                cn[c] = min(cn[c], (uint32_t)__shfl_xor((int)cn[c], o * 8, 64));
+                cm[c] = max(cm[c], (uint32_t)__shfl_xor((int)cm[c], o * 8, 64));
+            }
+        }
+        uint2 *lb = a.LB + ((size_t)f * a.t_stride + (size_t)blk * 64u) / 4u; // 16 per block
+        // a line with no cell inside the image gets the empty bounds {0,0}: never matches
+        if ((lane & 7u) == 0)
+            lb[lane >> 3] = rx[0] < rn[0] ? make_uint2(0u, 0u)
+                                          : make_uint2(pack_cell(rx[0], rx[1], rx[2]),
+                                                       pack_cell(rn[0], rn[1], rn[2]));
+        if (lane < 8u)
+            lb[8u + lane] = cm[0] < cn[0] ? make_uint2(0u, 0u)
+                                          : make_uint2(pack_cell(cm[0], cm[1], cm[2]),
+                                                       pack_cell(cn[0], cn[1], cn[2]));
+    }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         mn[c] = wave_min_u32(mn[c]);

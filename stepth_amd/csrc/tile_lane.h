@@ -58,51 +58,98 @@ STEPTH_HD int square_dmin(int x0, int y0, int side)
     return imax(dx, dy);
 }
 
-// 8-bit mask: cell p of the line lies in the box
-STEPTH_HD uint32_t line_hits(const uint32_t *c, uint32_t lo, uint32_t hi)
-{
+// The 8 cells of a line against the box.  Per cell r = (cell-lo) & (hi-cell) & guard; the cell
+// matches iff r == guard, and since every other subset of the three guard bits is numerically
+// smaller, "some cell of the line matches" is max(r) == guard: 3 instructions per cell plus 4
+// for the max.  Only a line that holds a match pays for the per-cell bits.
+struct LineTest {
+    uint32_t r[8];
+    STEPTH_HD void load(const uint32_t *c, uint32_t lo, uint32_t hi)
+    {
 #if defined(__HIP_DEVICE_COMPILE__)
-    const uint4 a = *reinterpret_cast<const uint4 *>(c), b = *reinterpret_cast<const uint4 *>(c + 4);
-    const uint32_t v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        const uint4 a = *reinterpret_cast<const uint4 *>(c), b = *reinterpret_cast<const uint4 *>(c + 4);
+        const uint32_t v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 #else
-    const uint32_t *v = c;
+        const uint32_t *v = c;
 #endif
-    uint32_t m = 0;
 #pragma unroll
-    for (int p = 7; p >= 0; --p)
-        m = m + m + (cell_in_box(v[p], lo, hi) ? 1u : 0u);
-    return m;
-}
+        for (int p = 0; p < 8; ++p)
+            r[p] = (v[p] - lo) & (hi - v[p]) & kGuard;
+    }
+    STEPTH_HD static uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
+    STEPTH_HD bool any() const
+    {
+        const uint32_t m0 = umax(umax(r[0], r[1]), r[2]), m1 = umax(umax(r[3], r[4]), r[5]);
+        return umax(umax(umax(r[6], r[7]), m0), m1) == kGuard;
+    }
+    STEPTH_HD uint32_t bits() const // bit p: cell p matches
+    {
+        uint32_t m = 0;
+#pragma unroll
+        for (int p = 7; p >= 0; --p)
+            m = m + m + (r[p] == kGuard ? 1u : 0u);
+        return m;
+    }
+};
 
-// Examines one block for query q.  (x0, y0) = offset of the block's cell (0,0) from the
-// centre; rows / cols = its 64 cells row-major (T) and column-major (TT); pb = position bits
-// of the key.  Returns the number of lines read (statistics).
-STEPTH_HD uint32_t probe_block(LaneQ &q, int x0, int y0, uint32_t pb, const uint32_t *rows,
-                               const uint32_t *cols)
+// One scan side of a block (SIDE 0: row y+s, 1: row y-s, 2: column x+s, 3: column x-s,
+// helpers.rs:28-31), nearest line first; stops at the first hit or at ring `limit`.
+// a0 / b0 = offset of the block's cell (0,0) across / along the lines, mdb = smallest |b| in
+// the block, lb = {max,min} bounds of the 8 lines (rows for sides 0/1, columns for 2/3): only
+// a line whose bounds meet the box is read.  Returns the lines read.
+template <int SIDE>
+STEPTH_HD uint32_t scan_side(LaneQ &q, int a0, int b0, int mdb, uint32_t pb, const uint32_t *tbl,
+                             const uint32_t *lb)
 {
+    constexpr bool neg = SIDE & 1;
+    constexpr int strict = SIDE < 2 ? 0 : 1; // corners belong to the rows (helpers.rs:28-31)
+    const int s_base = neg ? -(a0 + 7) : a0; // ring of the line with index 0 in scan order
+    const int first = imax(imax(s_base, 1), mdb + strict);
+    // lines i = 0..7 in scan order (i-th nearest), ring s_base + i; line i = row/column i of the
+    // block, or 7 - i on the sides that walk towards the centre's far side
+    if (first > s_base + 7 || (uint32_t)first >= q.limit)
+        return 0;
+    uint32_t cand = 0; // bit i: line i (scan order) may hold a match
+    {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const uint4 *l4 = reinterpret_cast<const uint4 *>(lb);
+        const uint4 w0 = l4[0], w1 = l4[1], w2 = l4[2], w3 = l4[3];
+        const uint32_t bx[8] = {w0.x, w0.z, w1.x, w1.z, w2.x, w2.z, w3.x, w3.z};
+        const uint32_t bn[8] = {w0.y, w0.w, w1.y, w1.w, w2.y, w2.w, w3.y, w3.w};
+#else
+        uint32_t bx[8], bn[8];
+        for (int i = 0; i < 8; ++i) {
+            bx[i] = lb[2 * i];
+            bn[i] = lb[2 * i + 1];
+        }
+#endif
+#pragma unroll
+        for (int i = 7; i >= 0; --i) { // highest scan index first: it ends in the highest bit
+            const int l = neg ? 7 - i : i;
+            cand = cand + cand + (box_meets(bx[l], bn[l], q.lo, q.hi) ? 1u : 0u);
+        }
+    }
+    cand &= 0xFFu << (first - s_base);
     uint32_t n_lines = 0;
 #pragma unroll 1
-    for (int side = 0; side < 4; ++side) {
-        const bool is_row = side < 2, neg = side & 1;
-        const int a0 = is_row ? y0 : x0; // coordinate across the lines
-        const int b0 = is_row ? x0 : y0; // coordinate along a line
-        const int strict = is_row ? 0 : 1; // corners belong to the rows (helpers.rs:28-31)
-        const int mdb = imax(imax(b0, -(b0 + 7)), 0);
-        int s = imax(imax(neg ? -(a0 + 7) : a0, 1), mdb + strict);
-        const int last = neg ? -a0 : a0 + 7;
-        const uint32_t *tbl = is_row ? rows : cols;
-#pragma unroll 1
-        for (; s <= last && (uint32_t)s < q.limit; ++s) {
-            const int line = (neg ? -s : s) - a0; // 0..7
-            const int r = s - strict;             // cells with |b| <= r belong to this side
+    while (cand) {
+        const int i = __builtin_ctz(cand);
+        cand &= cand - 1u;
+        const int s = s_base + i;
+        if ((uint32_t)s >= q.limit)
+            break;
+        const int line = neg ? 7 - i : i;
+        LineTest t;
+        t.load(tbl + line * 8, q.lo, q.hi);
+        ++n_lines;
+        if (t.any()) {
+            const int r = s - strict; // cells with |b| <= r belong to this side
             const int p0 = imax(0, -r - b0), p1 = imin(7, r - b0);
-            uint32_t hits = line_hits(tbl + line * 8, q.lo, q.hi);
-            hits &= (0xFFu >> (7 - p1)) & (0xFFu << p0);
-            ++n_lines;
+            const uint32_t hits = t.bits() & (0xFFu >> (7 - p1)) & (0xFFu << p0);
             if (hits) {
                 const int p = __builtin_ctz(hits);
                 const uint32_t key =
-                    ((((uint32_t)s << 2) | (uint32_t)side) << pb) | (uint32_t)(b0 + p + s);
+                    ((((uint32_t)s << 2) | (uint32_t)SIDE) << pb) | (uint32_t)(b0 + p + s);
                 q.best = key < q.best ? key : q.best;
                 q.limit = (uint32_t)s + 1u < q.limit ? (uint32_t)s + 1u : q.limit;
                 break;
@@ -110,6 +157,21 @@ STEPTH_HD uint32_t probe_block(LaneQ &q, int x0, int y0, uint32_t pb, const uint
         }
     }
     return n_lines;
+}
+
+// Examines one block for query q.  (x0, y0) = offset of the block's cell (0,0) from the
+// centre; rows / cols = its 64 cells row-major (T) and column-major (TT); lb = its 16 line
+// bounds (8 rows, then 8 columns; uint2 {max,min} each); pb = position bits of the key.
+// Returns the number of lines read (statistics).
+STEPTH_HD uint32_t probe_block(LaneQ &q, int x0, int y0, uint32_t pb, const uint32_t *rows,
+                               const uint32_t *cols, const uint32_t *lb)
+{
+    const int mdx = imax(imax(x0, -(x0 + 7)), 0), mdy = imax(imax(y0, -(y0 + 7)), 0);
+    uint32_t n = scan_side<0>(q, y0, x0, mdx, pb, rows, lb);
+    n += scan_side<1>(q, y0, x0, mdx, pb, rows, lb);
+    n += scan_side<2>(q, x0, y0, mdy, pb, cols, lb + 16);
+    n += scan_side<3>(q, x0, y0, mdy, pb, cols, lb + 16);
+    return n;
 }
 
 // Blocks of an 8x8-block window (block (0,0) of the window = block (bx0, by0) of the image)

@@ -33,6 +33,7 @@ extern "C" int tile_emulate(const uint8_t *main_px, uint32_t W, uint32_t H, uint
     const uint32_t bwp = tile_bwp(bw), bhp = tile_bhp(bh);
     std::vector<uint32_t> T((size_t)bw * bh * 64, kNoCell), TT((size_t)bw * bh * 64, kNoCell);
     std::vector<U2> BBp((size_t)bwp * bhp, U2{0, 0}), SB((size_t)sbw * sbh, U2{0, 0});
+    std::vector<U2> LB((size_t)bw * bh * 16, U2{0, 0}); // per block: 8 row bounds, 8 column bounds
     // pack (tile_pack_kernel / tile_super_kernel)
     for (uint32_t by = 0; by < bh; ++by)
         for (uint32_t bx = 0; bx < bw; ++bx) {
@@ -54,6 +55,24 @@ extern "C" int tile_emulate(const uint8_t *main_px, uint32_t W, uint32_t H, uint
             }
             BBp[(size_t)(by + kPadB) * bwp + bx + kPadB] =
                 U2{pack_cell(mx[0], mx[1], mx[2]), pack_cell(mn[0], mn[1], mn[2])};
+            for (uint32_t i = 0; i < 16; ++i) { // line bounds: rows 0..7, then columns 0..7
+                uint32_t ln[3] = {255, 255, 255}, lx[3] = {0, 0, 0};
+                bool any = false;
+                for (uint32_t p = 0; p < 8; ++p) {
+                    const uint32_t x = bx * 8 + (i < 8 ? p : i - 8), y = by * 8 + (i < 8 ? i : p);
+                    if (x >= wa || y >= ha)
+                        continue;
+                    any = true;
+                    const uint8_t *px = add + ((size_t)y * wa + x) * 3;
+                    for (int c = 0; c < 3; ++c) {
+                        ln[c] = std::min<uint32_t>(ln[c], px[c]);
+                        lx[c] = std::max<uint32_t>(lx[c], px[c]);
+                    }
+                }
+                if (any)
+                    LB[((size_t)by * bw + bx) * 16 + i] =
+                        U2{pack_cell(lx[0], lx[1], lx[2]), pack_cell(ln[0], ln[1], ln[2])};
+            }
         }
     for (uint32_t sy = 0; sy < sbh; ++sy)
         for (uint32_t sx = 0; sx < sbw; ++sx) {
@@ -217,7 +236,8 @@ extern "C" int tile_emulate(const uint8_t *main_px, uint32_t W, uint32_t H, uint
                                         if (bx < 0 || by < 0 || bx >= (int)bw || by >= (int)bh)
                                             return -2; // a padded block got through: memory fault on the GPU
                                         const size_t boff = ((size_t)by * bw + bx) * 64;
-                                        n_lines += probe_block(q[l], x0, y0, pb, &T[boff], &TT[boff]);
+                                        n_lines += probe_block(q[l], x0, y0, pb, &T[boff], &TT[boff],
+                                                               reinterpret_cast<const uint32_t *>(&LB[boff / 4]));
                                         ++n_probes;
                                     }
                                 }
