@@ -88,7 +88,7 @@ __device__ __forceinline__ uint32_t test_half_row(uint32_t acc, uint32_t b0x, ui
 #define STEPTH_BT(MX, MN)                                                                      \
     "v_sub_u32 %1, " MX ", %3\n v_subrev_u32 %2, " MN ", %4\n v_and_or_b32 %1, %1, %2, %5\n"    \
     "v_cmp_eq_u32 vcc, -1, %1\n v_addc_co_u32 %0, vcc, %0, %0, vcc\n"
-    asm volatile(STEPTH_BT("%12", "%13") STEPTH_BT("%10", "%11") STEPTH_BT("%8", "%9")
+    asm(STEPTH_BT("%12", "%13") STEPTH_BT("%10", "%11") STEPTH_BT("%8", "%9")
                      STEPTH_BT("%6", "%7")
                  : "+v"(acc), "=&v"(t), "=&v"(u)
                  : "v"(lo), "v"(hi), "s"(ng), "s"(b0x), "s"(b0y), "s"(b1x), "s"(b1y), "s"(b2x),
@@ -214,14 +214,20 @@ __global__ __launch_bounds__(256) void ring_tile_kernel(TileArgs a)
                     [[maybe_unused]] const unsigned long long pc_s0 = STEPTH_TICK();
                     for (int ty = 0; ty < nsy; ++ty) {
                         const int sy = sy0 + ty;
-                        const uint2 *sbrow = SBf + (size_t)sy * a.sbwp + sx0;
+                        // a row of the window in one go: up to 10 superblocks = 20 dwords
+                        const uint4 *sb4 = reinterpret_cast<const uint4 *>(SBf + (size_t)sy * a.sbwp + sx0);
+                        const uint4 g0 = sb4[0], g1 = sb4[1], g2 = sb4[2], g3 = sb4[3], g4 = sb4[4];
                         const int ay = (sy << 6) - q.qy;
                         const int dsy = max(max(ay, -63 - ay), 0);
-                        for (int tx = 0; tx < nsx; ++tx) {
-                            const uint2 sb = sbrow[tx];
+                        const uint32_t sbv[20] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w, g2.x, g2.y,
+                                                  g2.z, g2.w, g3.x, g3.y, g3.z, g3.w, g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+                        for (int tx = 0; tx < 10; ++tx) {
+                            if (tx >= nsx)
+                                break;
                             const int ax = ((sx0 + tx) << 6) - q.qx;
                             const uint32_t dS = (uint32_t)max(max(max(ax, -63 - ax), 0), dsy);
-                            const bool w = dS < q.limit && box_meets(sb.x, sb.y, q.lo, q.hi);
+                            const bool w = dS < q.limit && box_meets(sbv[2 * tx], sbv[2 * tx + 1], q.lo, q.hi);
                             if constexpr (STATS)
                                 n_tests += q.limit != 0u;
                             if (__builtin_amdgcn_ballot_w64(w)) {
@@ -243,9 +249,11 @@ __global__ __launch_bounds__(256) void ring_tile_kernel(TileArgs a)
                     }
                     pc_survey += STEPTH_TICK() - pc_s0;
                 }
-                // nearest superblock some lane may still want
+                // nearest superblock some lane may still want.  Slots come in the order of their
+                // distance from the middle of the wave's centres, which is within 4 rings of
+                // every lane's own distance: past the largest limit + 4 nothing is left.
                 const uint32_t pick = wave_min_dpp(min(min(skey0, skey1), skey2));
-                if (pick == kTileNoKey)
+                if (pick == kTileNoKey || (pick >> 8) >= wave_max_dpp(q.limit) + 4u)
                     break;
                 skey0 = skey0 == pick ? kTileNoKey : skey0;
                 skey1 = skey1 == pick ? kTileNoKey : skey1;
@@ -271,13 +279,13 @@ __global__ __launch_bounds__(256) void ring_tile_kernel(TileArgs a)
             // (wave-uniform: distances from the wave's 8x2 centres).
             uint32_t m_lo = 0, m_hi = 0; // bit row*8+col
             [[maybe_unused]] const unsigned long long pc_b0 = STEPTH_TICK();
+            const uint32_t wlim = wave_max_dpp(want ? q.limit : 0u);
             {
-                const uint32_t wlim = wave_max_dpp(want ? q.limit : 0u);
                 const int cx_l = bx0 * 8 - (wx0 + 7), cx_r = wx0 - (bx0 * 8 + 31); // cols 0..3
                 const bool need_l = max(max(cx_l, cx_r), 0) < (int)wlim;
                 const bool need_h = max(max(cx_l + 32, cx_r - 32), 0) < (int)wlim;   // cols 4..7
                 const uint2 *win = BBf + (size_t)(by0 + kPadB) * a.bwp + (size_t)(bx0 + kPadB);
-                auto do_row = [&](uint32_t acc, int row) -> uint32_t {
+                auto do_row = [&](uint32_t acc, int row) __attribute__((always_inline)) -> uint32_t {
                     const int ry0 = (by0 + row) * 8 - (wy0 + 1), ry1 = wy0 - ((by0 + row) * 8 + 7);
                     if (max(max(ry0, ry1), 0) >= (int)wlim || (it == 0 && row == 7))
                         return acc << 8;
@@ -316,6 +324,8 @@ __global__ __launch_bounds__(256) void ring_tile_kernel(TileArgs a)
                 uint64_t cur = cand & le & ~le_prev;
                 le_prev = le;
                 // a block of block-ring r has no cell nearer than ring 8(r-1)+1
+                if (8 * (r - 1) + 1 >= (int)wlim)
+                    break; // (wlim: the lanes' largest limit when the step began)
                 if (8 * (r - 1) + 1 >= (int)q.limit)
                     cur = 0ull;
                 if (!__builtin_amdgcn_ballot_w64(cur != 0ull))
