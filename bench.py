@@ -5,26 +5,33 @@ Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 la
 torch.distributed.run, one rank per GPU.  Rank 0 prints ONE JSON line.
 
 Workload (BASELINE.json metric: "Mpixels/sec depth output, 1080p stereo d_max=128"):
-  a step = one pass of the hot path over a batch of `8 * N` synthetic 1920x1080
-  stereo pairs (inputs resident in HBM), reference-exact mode (square-ring first hit,
+  a step = one pass of the hot path over a batch of `8 * N` synthetic 1920x1080 stereo pairs
+  (inputs resident in HBM), reference-exact mode (square-ring first hit,
   /root/reference/src/helpers.rs:9-54), one group per pixel, max_steps = d_max = 128,
   precision [36;3] (Readme.md:14).  All frames of a step go through ONE set of launches
-  (stepth_depth_from_additional_batch): pack additional -> ring0 (centre cell + compaction)
-  -> ring_search -> ring_finish (distance, max per frame) -> normalise -> depth rows.  With N > 1 every frame is sharded by row strips over the N ranks,
-  with one all_reduce(MAX) and one gather of the depth rows to rank 0 per step (RCCL); per-GPU work is
-  constant in N (weak scaling).  value = frames * 1920*1080 / step time, whole job.
-
-  --mode sad runs the windowed-SAD mode (5x5, d_max=128) instead; it has no counterpart in the
-  reference and is reported under its own metric name.
+  (stepth_depth_from_additional_batch): pack additional -> dense ring search (ring 0, search,
+  distance, max per frame: ring_tile_kernel) -> normalise + paint.  With N > 1 every frame is
+  sharded by row strips over the N ranks, with one all_reduce(MAX) and one gather of the depth
+  rows to rank 0 per step (RCCL); per-GPU work is constant in N (weak scaling).
+  value = frames * 1920*1080 / step time, whole job.
 
 roofline: HBM-bound by contract (scan/compare, no MFMA).  achieved = algorithmic bytes per
-  ring_search launch (7 B per output pixel: 3 B main RGB + 3 B additional RGB + 1 B depth,
+  ring_tile_kernel launch (7 B per output pixel: 3 B main RGB + 3 B additional RGB + 1 B depth,
   SURVEY.md 8d) / that kernel's mean launch time, measured live with HIP events on the
-  engine's stream; peak = 8 TB/s.  The ring search is data dependent, so the mean number of
-  probes per pixel is printed next to it.
+  engine's stream; peak = 8 TB/s.  The ring search is data dependent, so the number of items
+  examined per pixel is printed next to it.  `traffic` = HBM bytes per launch from the
+  committed rocprofv3 PMC passes (profiles/r2_hbm_traffic.json), valid for the profiled shape.
 cpu_baseline: the C restatement of the reference algorithm (oracle/, "port" -- NOT the Rust
   binary) on one frame of the same workload, all host cores with dynamic scheduling, plus the
   reference's own static 8-chunk partition (src/depth_image.rs:111-112) as `ref8_value`.
+
+Extra objects (N = 1, outside the timed region, each a few launches): `two_streams`,
+`config2_1080p_d64`, `config3_4k_d128` (north_star's target configuration),
+`config5_8k_d256_1gpu`, `asset_tiled_1080p` (the reference's own image pair, mirror-tiled),
+`adaptive_flow` (grouping -> match -> normalise -> paint, the way the reference runs),
+`end_to_end` (host-resident frames, PCIe-inclusive), `sad_mode`, `with_gaussian_tail`,
+`foreground_tail`.  Every ring leg carries its own kernel time, Mpixels/s, HBM fraction and a
+bit-exact flag against the oracle (whole frame 0 at 1080p, 20 000 sampled pixels above).
 """
 import argparse
 import json
@@ -36,9 +43,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# The steps alternate over two HIP streams (see main); with the runtime's default of 4 hardware
-# queues the two streams sometimes end up on the same queue and serialise, with 8 they do not.
-# Must be set before the HIP runtime starts, i.e. before torch is imported.
+# With several HIP streams in use (--streams 2) the runtime's default of 4 hardware queues
+# sometimes puts two streams on one queue and serialises them; 8 do not.  Must be set before
+# the HIP runtime starts, i.e. before torch is imported.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np
@@ -47,24 +54,48 @@ import torch.distributed as dist
 
 HBM_PEAK_GBS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
 ALGO_BYTES_PER_PIXEL = 7.0
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r2_hbm_traffic.json")
+DOMINANT_KERNEL = "ring_tile_kernel"  # tests/test_bench_contract.py checks the profile names it
 
 
-def make_frames(width, height, d_max, count):
-    """`count` distinct synthetic pairs from two seeded base pairs and their flips."""
+def flips():
+    return [lambda a: a, lambda a: a[:, ::-1], lambda a: a[::-1], lambda a: a[::-1, ::-1]]
+
+
+def make_frames(width, height, d_max, count, seed0=0x5EED, bases=2):
+    """`count` distinct synthetic pairs from `bases` seeded base pairs and their flips."""
     from stepth_amd import synth
-    bases = [synth.stereo_pair(width, height, d_max, seed=0x5EED + i)[:2]
-             for i in range(min(2, count))]
-    flips = [lambda a: a, lambda a: a[:, ::-1], lambda a: a[::-1], lambda a: a[::-1, ::-1]]
+    base = [synth.stereo_pair(width, height, d_max, seed=seed0 + i)[:2]
+            for i in range(min(bases, count))]
     frames = []
     for i in range(count):
-        l, r = bases[i % len(bases)]
-        f = flips[(i // len(bases)) % 4]
+        l, r = base[i % len(base)]
+        f = flips()[(i // len(base)) % 4]
         frames.append((np.ascontiguousarray(f(l)), np.ascontiguousarray(f(r))))
     return frames
 
 
-def cpu_baseline(frame, args):
-    """Times the oracle (test infrastructure; allowed here as the CPU baseline) on one frame."""
+def mirror_tile(img, width, height):
+    """`img` continued by mirroring to width x height (seamless: no artificial edges)"""
+    a = np.concatenate([img, img[:, ::-1]], 1)
+    a = np.concatenate([a, a[::-1]], 0)
+    ry, rx = -(-height // a.shape[0]), -(-width // a.shape[1])
+    return np.ascontiguousarray(np.tile(a, (ry, rx, 1))[:height, :width])
+
+
+def asset_frames(width, height, count):
+    """the reference's own pair (assets/main.jpg + additional.jpg, committed decoded as
+    tests/golden/asset_*.png) mirror-tiled to width x height, `count` frames by flips"""
+    from PIL import Image
+    g = os.path.join(ROOT, "tests", "golden")
+    m = np.asarray(Image.open(os.path.join(g, "asset_main.png")))[..., :3]
+    a = np.asarray(Image.open(os.path.join(g, "asset_additional.png")))[..., :3]
+    m, a = mirror_tile(m, width, height), mirror_tile(a, width, height)
+    return [(np.ascontiguousarray(flips()[i % 4](m)), np.ascontiguousarray(flips()[i % 4](a)))
+            for i in range(count)]
+
+
+def load_oracle():
     from oracle import oracle as O
     try:  # a host-tuned build of the same C file, kept out of the tree
         lib_path = O.build(force=True, lib_path=os.path.join("/tmp", f"stepth_oracle_native_{os.getpid()}.so"),
@@ -73,6 +104,11 @@ def cpu_baseline(frame, args):
     except Exception:
         O.lib()
     O.set_threads(O.usable_cpus())
+    return O
+
+
+def cpu_baseline(O, frame, args):
+    """Times the oracle (test infrastructure; allowed here as the CPU baseline) on one frame."""
     l, r = frame
     prec = [args.precision] * 3
     if args.mode == "ring":
@@ -90,7 +126,7 @@ def cpu_baseline(frame, args):
                "seconds": round(t_all, 3),
                "ref8_value": round(px / t_ref8 / 1e6, 4),
                "ref8_note": "static len/8 chunks like src/depth_image.rs:111-112 (9 threads max)",
-               "probes_per_pixel": round(ref["probes"] / px, 1)}
+               "reference_probes_per_pixel": round(ref["probes"] / px, 1)}
         return out, ref["depth"]
     rows = min(l.shape[0], 32)  # SAD on CPU is ~1e3x slower: a 32-row band
     t0 = time.perf_counter()
@@ -101,6 +137,69 @@ def cpu_baseline(frame, args):
            "sample": f"rows 0..{rows} of 1 frame {l.shape[1]}x{l.shape[0]}, all cores",
            "seconds": round(t_all, 3)}
     return out, raw[:rows]
+
+
+def sampled_raw_check(O, raw_gpu, main, add, prec, max_steps, n=20000, seed=1):
+    """GPU raw distances == oracle on `n` random pixels (1x1 groups, src/depth_image.rs:112-121)"""
+    h, w = main.shape[:2]
+    rng = np.random.default_rng(seed)
+    ys, xs = rng.integers(0, h, n), rng.integers(0, w, n)
+    g = np.zeros(n, O.GROUP_DTYPE)
+    g["x"], g["y"], g["w"], g["h"] = xs, ys, 1, 1
+    g["value"] = main[ys, xs, :3]
+    res = O.match_groups(g, add, max_steps, prec)
+    return bool(np.array_equal(res["raw"], raw_gpu[ys, xs])), res["probes"] / n
+
+
+def ring_leg(eng, O, frames_np, prec, max_steps, reps, check, dev, label):
+    """one batched call per repetition on device-resident frames; -> dict for the JSON line"""
+    from stepth_amd import Engine  # noqa: F401
+    h, w = frames_np[0][0].shape[:2]
+    mains = [torch.from_numpy(l).to(dev) for l, _ in frames_np]
+    adds = [torch.from_numpy(r).to(dev) for _, r in frames_np]
+    outs = [torch.empty((h, w), dtype=torch.uint8, device=dev) for _ in frames_np]
+    n = len(frames_np)
+
+    def call(**kw):
+        return eng.depth_from_additional_batch(mains, adds, prec, max_steps=max_steps, outs=outs,
+                                               asynchronous=True, **kw)
+    call()
+    torch.cuda.synchronize()
+    eng.kernel_time_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        call()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    kms, kl = eng.kernel_time_read()
+    eng.kernel_time_enable(False)
+    k_avg = kms / max(kl, 1)
+    px = n * w * h
+    out = {"value": round(px / dt / 1e6, 1), "unit": "Mpixels/s", "workload": label,
+           "frames_per_launch": n // max(kl // reps, 1), "ms_per_call": round(dt * 1e3, 4),
+           "kernel": DOMINANT_KERNEL, "kernel_avg_ms": round(k_avg, 4),
+           "hbm_frac": round(ALGO_BYTES_PER_PIXEL * px / max(kl // reps, 1) / (k_avg * 1e-3) / 1e9
+                             / HBM_PEAK_GBS, 6)}
+    eng.stats_enable(True)
+    call()
+    st = eng.stats()
+    eng.stats_enable(False)
+    out["gpu_items_examined_per_pixel"] = round(st["probes"] / max(st["groups"], 1), 1)
+    out["gpu_blocks_probed_per_pixel"] = round(st["blocks_probed"] / max(st["groups"], 1), 3)
+    out["ring0_hit_fraction"] = round(st["ring0_hits"] / max(st["groups"], 1), 4)
+    if check == "full":
+        depth, _ = eng.depth_from_additional_batch(mains[:1], adds[:1], prec, max_steps=max_steps)
+        ref = O.depth_from_additional(frames_np[0][0], frames_np[0][1], prec, max_steps, (1, 1))
+        out["parity_frame0_bit_exact"] = bool(np.array_equal(depth[0].cpu().numpy(), ref["depth"]))
+        out["reference_probes_per_pixel"] = round(ref["probes"] / (w * h), 1)
+    elif check == "sample":
+        raw, _ = eng.depth_from_additional_batch(mains[:1], adds[:1], prec, max_steps=max_steps,
+                                                 raw_only=True)
+        ok, ppp = sampled_raw_check(O, raw[0].cpu().numpy(), frames_np[0][0], frames_np[0][1], prec,
+                                    max_steps)
+        out["parity_20000_sampled_pixels_bit_exact"] = ok
+        out["reference_probes_per_pixel"] = round(ppp, 1)
+    return out
 
 
 def main():
@@ -117,13 +216,19 @@ def main():
     ap.add_argument("--frames-per-gpu", dest="fpg", type=int, default=8,
                     help="frames per step and GPU (BASELINE config 4: 64 pairs over 8 GPUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="N = 1: only the headline (skips the other configurations)")
     ap.add_argument("--interleave", type=int, default=0,
                     help="N > 1, ring mode: deal rows in interleaved blocks of this many rows "
-                         "(0 = contiguous strips, a few % faster on the bench frames; blocks of 16 "
-                         "balance the data-dependent work whatever the image content)")
-    ap.add_argument("--streams", type=int, default=2,
+                         "(0 = contiguous strips; blocks of 16 balance the data-dependent work "
+                         "whatever the image content)")
+    ap.add_argument("--streams", type=int, default=1,
                     help="steps alternate over this many engines/HIP streams (1 = strictly one "
-                         "step after the other)")
+                         "step after the other, the headline; 2 is reported as `two_streams`)")
+    ap.add_argument("--rotate-frames", dest="rotate", type=int, default=3,
+                    help="N > 1: cycle through this many distinct frame sets, so that the strip "
+                         "balancer faces content that changes from step to step (1 = the same "
+                         "frames every step)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="N > 1: finish every step's gather before the next step starts")
     ap.add_argument("--no-balance", action="store_true",
@@ -160,107 +265,112 @@ def main():
 
     W, H = args.width, args.height
     n_frames = args.fpg * world
-    frames_np = make_frames(W, H, args.d_max, n_frames)
-    frames = [(torch.from_numpy(l).to(dev), torch.from_numpy(r).to(dev)) for l, r in frames_np]
-
-    # Steps alternate over `--streams` engines, each on its own HIP stream: while one step's
-    # search kernel drains, the next step's pack / ring-0 kernels (HBM-bound) and the previous
-    # step's finish / paint already run -- two batches in flight, like any streaming pipeline.
-    n_slots = max(1, args.streams)
-    torch.cuda.synchronize()  # the uploads above
-    engines = [Engine(local_rank) for _ in range(n_slots)]
-    streams = [torch.cuda.Stream(device=dev) for _ in range(n_slots)] if n_slots > 1 else [None]
-    for e_, s_ in zip(engines, streams):
-        if s_ is None:
-            e_.use_torch_stream()
-        else:
-            with torch.cuda.stream(s_):
-                e_.use_torch_stream()
-    eng = engines[0]
+    # N > 1: `rotate` distinct frame sets (different seeds), cycled step by step
+    n_sets = max(1, args.rotate) if world > 1 else 1
+    sets_np = [make_frames(W, H, args.d_max, n_frames, seed0=0x5EED + 2 * k) for k in range(n_sets)]
+    frames_np = sets_np[0]
+    frame_sets = [[(torch.from_numpy(l).to(dev), torch.from_numpy(r).to(dev)) for l, r in s]
+                  for s in sets_np]
     prec = [args.precision] * 3
 
-    def make_worker(e_):
-        if args.mode == "ring":
-            return EngineStripWorker(e_, prec, max_steps=args.d_max, tile=(1, 1), mode=MODE_RING_FIRST_HIT)
-        return EngineStripWorker(e_, prec, mode=MODE_SAD_WINDOW, d_max=args.d_max, win=args.win)
-
-    workers = [make_worker(e_) for e_ in engines]
-    worker = workers[0]
-
-    # N > 1, contiguous strips: the cut points follow the ranks' measured times from step to
-    # step (the cost of a row is data dependent); the warm-up steps let them settle
-    balancer = StripBalancer(H, world, align=2, lag=n_slots) if world > 1 and not args.interleave \
-        and not args.no_balance else None
-
-    # N > 1: the gather of a step's rows to rank 0 runs behind the following kernels; the
-    # outstanding gathers are flushed inside the timed region
-    pipelines = [GatherPipeline() if world > 1 and not args.interleave and not args.no_overlap
-                 else None for _ in range(n_slots)]
-    pipeline = pipelines[0]
-    step_no = [0]
-
-    def step():
-        slot = step_no[0] % n_slots
-        step_no[0] += 1
-
-        def run():
-            return sharded_depth(workers[slot], frames, H, W, dst=0 if world > 1 else None,
-                                 interleave=args.interleave if args.mode == "ring" else 0,
-                                 balancer=balancer, pipeline=pipelines[slot])
-        if streams[slot] is None:
-            return run()
-        with torch.cuda.stream(streams[slot]):
-            return run()
-
-    def flush():
-        """finishes the gathers still in flight, oldest first; -> depth maps of the last step"""
-        last = None
-        for k in range(n_slots):
-            slot = (step_no[0] + k) % n_slots  # the slot of the oldest outstanding step first
-            if pipelines[slot] is None:
-                continue
-            if streams[slot] is None:
-                d = pipelines[slot].flush()
+    def run_timed(n_slots, steps, warmup):
+        """`steps` timed steps alternating over n_slots engines / HIP streams
+        -> (seconds, kernel ms, kernel launches, depth of the last step, max, balancer)"""
+        torch.cuda.synchronize()
+        engines = [Engine(local_rank) for _ in range(n_slots)]
+        streams = [torch.cuda.Stream(device=dev) for _ in range(n_slots)] if n_slots > 1 else [None]
+        for e_, s_ in zip(engines, streams):
+            if s_ is None:
+                e_.use_torch_stream()
             else:
-                with torch.cuda.stream(streams[slot]):
+                with torch.cuda.stream(s_):
+                    e_.use_torch_stream()
+
+        def make_worker(e_):
+            if args.mode == "ring":
+                return EngineStripWorker(e_, prec, max_steps=args.d_max, tile=(1, 1), mode=MODE_RING_FIRST_HIT)
+            return EngineStripWorker(e_, prec, mode=MODE_SAD_WINDOW, d_max=args.d_max, win=args.win)
+
+        workers = [make_worker(e_) for e_ in engines]
+        # N > 1, contiguous strips: the cut points follow the ranks' measured times from step
+        # to step (the cost of a row is data dependent); the warm-up steps let them settle
+        balancer = StripBalancer(H, world, align=2, lag=n_slots) if world > 1 and not args.interleave \
+            and not args.no_balance else None
+        # N > 1: the gather of a step's rows to rank 0 runs behind the following kernels; the
+        # outstanding gathers are flushed inside the timed region
+        pipelines = [GatherPipeline() if world > 1 and not args.interleave and not args.no_overlap
+                     else None for _ in range(n_slots)]
+        step_no = [0]
+
+        def step():
+            slot = step_no[0] % n_slots
+            frames = frame_sets[step_no[0] % n_sets]
+            step_no[0] += 1
+
+            def run():
+                return sharded_depth(workers[slot], frames, H, W, dst=0 if world > 1 else None,
+                                     interleave=args.interleave if args.mode == "ring" else 0,
+                                     balancer=balancer, pipeline=pipelines[slot])
+            if streams[slot] is None:
+                return run()
+            with torch.cuda.stream(streams[slot]):
+                return run()
+
+        def flush():
+            """finishes the gathers still in flight, oldest first; -> depth of the last step"""
+            last = None
+            for k in range(n_slots):
+                slot = (step_no[0] + k) % n_slots  # the slot of the oldest outstanding step first
+                if pipelines[slot] is None:
+                    continue
+                if streams[slot] is None:
                     d = pipelines[slot].flush()
-            if slot == (step_no[0] - 1) % n_slots:
-                last = d
-        return last
+                else:
+                    with torch.cuda.stream(streams[slot]):
+                        d = pipelines[slot].flush()
+                if slot == (step_no[0] - 1) % n_slots:
+                    last = d
+            return last
 
-    def fence():
-        torch.cuda.synchronize()
+        def fence():
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        depth = mx = None
+        for _ in range(warmup):
+            depth, mx = step()
+        if pipelines[0] is not None:
+            flush()
+        fence()
+        for e_ in engines:
+            e_.kernel_time_enable(True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            depth, mx = step()
+        if pipelines[0] is not None:
+            depth = flush()  # the last step's rows; part of the timed work
+        fence()
+        dt = time.perf_counter() - t0
+        kms = kl = 0
+        for e_ in engines:
+            k_, l_ = e_.kernel_time_read()
+            kms, kl = kms + k_, kl + l_
+            e_.kernel_time_enable(False)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
         if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        last_set = (step_no[0] - 1) % n_sets
+        for e_ in engines[1:]:
+            e_.close()
+        return float(t.item()), kms, kl, depth, mx, balancer, engines[0], workers[0], last_set
 
-    depth = None
-    for _ in range(args.warmup):
-        depth, _mx = step()
-    if pipeline is not None:
-        flush()
-    fence()
-    for e_ in engines:
-        e_.kernel_time_enable(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        depth, _mx = step()
-    if pipeline is not None:
-        depth = flush()  # the last step's rows; part of the timed work
-    fence()
-    dt = time.perf_counter() - t0
-    kms = klaunches = 0
-    for e_ in engines:
-        k_, l_ = e_.kernel_time_read()
-        kms, klaunches = kms + k_, klaunches + l_
-        e_.kernel_time_enable(False)
+    dt, kms, klaunches, depth, _mx, balancer, eng, worker, last_set = run_timed(
+        max(1, args.streams), args.steps, args.warmup)
     eng.use_torch_stream()  # the extra legs below run on the default stream
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
 
-    # probes/pixel of this rank's strips (data-dependent work), outside the timed region
+    # items examined per pixel on this rank's strips (data-dependent work), outside the timed region
     probes_pp = None
     if args.mode == "ring":
         r0, r1 = (balancer.bounds if balancer is not None else strip_bounds(H, world))[rank]
@@ -269,7 +379,7 @@ def main():
             r0, r1, pat = 0, H, (args.interleave, world, rank)
         eng.stats_enable(True)
         tot_p = tot_g = 0
-        for f in frames[: min(len(frames), 8)]:
+        for f in frame_sets[0][: min(n_frames, 8)]:
             worker.match_strip(f, (r0, r1), pattern=pat)
             s = eng.stats()
             tot_p += s["probes"]
@@ -287,15 +397,15 @@ def main():
         k_avg_ms = kms / max(klaunches, 1)
         achieved = ALGO_BYTES_PER_PIXEL * px_launch / (k_avg_ms * 1e-3) / 1e9 if klaunches else 0.0
         # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE,
-        # gfx950-corrected; see profiles/r1_ring_hbm_traffic.json) -- only for the profiled shape
+        # gfx950-corrected) -- only for the shape that was profiled
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r1_ring_hbm_traffic.json")
         if args.mode == "ring" and world == 1 and (W, H, args.d_max) == (1920, 1080, 128) \
-                and os.path.exists(tpath):
-            prof = json.load(open(tpath))
-            per_launch = prof.get("ring_search_kernel_traffic_bytes_per_launch_corrected")
-            if per_launch and prof.get("frames_per_launch"):  # scale to this run's batch size
+                and os.path.exists(TRAFFIC_FILE):
+            prof = json.load(open(TRAFFIC_FILE))
+            per_launch = prof.get("dominant_kernel_traffic_bytes_per_launch_corrected")
+            if per_launch and prof.get("frames_per_launch") and DOMINANT_KERNEL in prof.get("dominant_kernel", ""):
                 traffic = int(per_launch * frames_per_launch / prof["frames_per_launch"])
+        n_slots = max(1, args.streams)
         out = {
             "metric": ("Mpixels/sec depth output, 1080p stereo d_max=128" if args.mode == "ring"
                        else "Mpixels/sec depth output, windowed-SAD mode (not in the reference)"),
@@ -314,29 +424,133 @@ def main():
                              + f", precision [{args.precision};3]"),
                 "frames_per_step": n_frames, "width": W, "height": H, "d_max": args.d_max,
                 "mode": args.mode,
+                "frame_sets_cycled": n_sets,
                 "parallelism": ((f"interleaved {args.interleave}-row strips" if args.interleave and args.mode == "ring"
                                  else "contiguous row strips, cut points following measured per-rank times"
                                  if balancer is not None else "contiguous row strips")
                                 + f" x{world} + all_reduce(max) + gather of rows to rank 0 (RCCL"
-                                + (", overlapped with the next step's kernels)" if pipeline is not None else ")")
+                                + (", overlapped with the next step's kernels)" if not args.no_overlap and not args.interleave else ")")
                                 if world > 1 else "single GPU")
-                               + (f"; steps alternate over {n_slots} engines/HIP streams" if n_slots > 1 else ""),
+                               + (f"; steps alternate over {n_slots} engines/HIP streams" if n_slots > 1
+                                  else "; one HIP stream"),
             },
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                "kernel": "ring_search_kernel" if args.mode == "ring" else "sad_search_kernel",
+                "kernel": DOMINANT_KERNEL if args.mode == "ring" else "sad_search_kernel",
                 "kernel_avg_ms": round(k_avg_ms, 4), "kernel_launches": klaunches,
                 "frames_per_launch": frames_per_launch,
                 "algorithmic_bytes_per_launch": ALGO_BYTES_PER_PIXEL * px_launch,
-                "probes_per_pixel": None if probes_pp is None else round(probes_pp, 1),
+                "gpu_items_examined_per_pixel": None if probes_pp is None else round(probes_pp, 1),
+                "note": "items = bound tests + cells the GPU search examined per pixel; the "
+                        "reference's own probe count for the same frame is "
+                        "cpu_baseline.reference_probes_per_pixel",
             },
         }
-        if args.mode == "ring" and world == 1:
-            # the engine's second mode on the same frames (north_star's literal windowed SAD;
-            # no counterpart in the reference): a short extra leg, outside the timed region
-            sworker = EngineStripWorker(eng, prec, mode=MODE_SAD_WINDOW, d_max=args.d_max,
-                                        win=args.win)
+        O = None
+        if not args.no_cpu_baseline:
+            O = load_oracle()
+        extra = args.mode == "ring" and world == 1 and not args.no_extra_legs
+        if extra:
+            # -- the same headline with two steps in flight on two HIP streams
+            dt2, kms2, kl2, _d2, _m2, _b2, eng2, _w2, _ls = run_timed(2, args.steps, args.warmup)
+            eng2.close()
+            out["two_streams"] = {
+                "value": round(px_step * args.steps / dt2 / 1e6, 1), "unit": "Mpixels/s",
+                "ms_per_step": round(dt2 / args.steps * 1e3, 4),
+                "note": "steps alternate over 2 engines on 2 HIP streams; their dominant kernels "
+                        "overlap, so the per-launch time is not comparable with the headline's",
+                "kernel_avg_ms_overlapped": round(kms2 / max(kl2, 1), 4)}
+        if extra and O is not None:
+            # -- the other BASELINE.json configurations and the reference's own image pair
+            out["config2_1080p_d64"] = ring_leg(
+                eng, O, frames_np, prec, 64, 5, "full", dev,
+                f"{n_frames} x 1920x1080 synthetic pairs, ring first-hit, max_steps=d_max=64")
+            out["asset_tiled_1080p"] = ring_leg(
+                eng, O, asset_frames(1920, 1080, 8), prec, 128, 5, "full", dev,
+                "8 x 1920x1080 = the reference's assets/main.jpg + additional.jpg mirror-tiled "
+                "(natural image statistics), ring first-hit, max_steps=128")
+            out["asset_tiled_1080p_max255"] = ring_leg(
+                eng, O, asset_frames(1920, 1080, 8), prec, 255, 5, "sample", dev,
+                "same frames, max_steps=255 (the reference's own reach, src/depth_image.rs:119)")
+            f4k = make_frames(3840, 2160, 128, 4, bases=1)
+            out["config3_4k_d128"] = ring_leg(
+                eng, O, f4k, prec, 128, 3, "sample", dev,
+                "4 x 3840x2160 synthetic pairs (1 seed + flips), ring first-hit, max_steps=d_max=128 "
+                "(north_star's target configuration)")
+            # 8K: the 4K pair continued by mirroring (generating 8K value noise takes minutes)
+            f8k = [(mirror_tile(f4k[0][0], 7680, 4320), mirror_tile(f4k[0][1], 7680, 4320))]
+            out["config5_8k_d256_1gpu"] = ring_leg(
+                eng, O, f8k, prec, 256, 3, "sample", dev,
+                "1 x 7680x4320 pair (the 4K synthetic pair mirror-tiled 2x2), ring first-hit, "
+                "max_steps=d_max=256, one frame per launch")
+            del f4k, f8k
+        if extra:
+            frames = frame_sets[0]
+            # -- the path the way the reference runs it: adaptive pixel groups (the engine's
+            # stand-in for disage, src/depth_image.rs:101-110) -> match -> normalise -> paint,
+            # all frames through the batched entry points
+            mains_t, adds_t = [f[0] for f in frames], [f[1] for f in frames]
+            outs_t = [torch.empty((H, W), dtype=torch.uint8, device=dev) for _ in frames]
+            if hasattr(eng, "adaptive_depth_batch"):
+                def flow():
+                    eng.adaptive_depth_batch(mains_t, adds_t, prec, max_steps=args.d_max, outs=outs_t,
+                                             asynchronous=True)
+                flow()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(5):
+                    flow()
+                torch.cuda.synchronize()
+                adt = (time.perf_counter() - t1) / 5
+                out["adaptive_flow"] = {
+                    "value": round(px_step / adt / 1e6, 1), "unit": "Mpixels/s",
+                    "ms_per_call": round(adt * 1e3, 4),
+                    "workload": f"{n_frames} frames: stepth_adaptive_groups_batch -> ring first-hit per "
+                                "group -> normalise -> paint, groups never leave the device "
+                                "(grouping rule: this engine's own, parity with disage unpinned)"}
+                if O is not None:
+                    d0, _ = eng.adaptive_depth_batch(mains_t[:1], adds_t[:1], prec, max_steps=args.d_max)
+                    g = O.adaptive_groups(frames_np[0][0], prec)
+                    ref = O.depth_from_additional(frames_np[0][0], frames_np[0][1], prec, args.d_max, groups=g)
+                    out["adaptive_flow"]["parity_frame0_bit_exact"] = bool(
+                        np.array_equal(d0[0].cpu().numpy(), ref["depth"]))
+                    out["adaptive_flow"]["groups_frame0"] = int(len(g))
+            # -- host-resident frames through the pipelined host batch (the
+            # end-to-end, PCIe-inclusive rate; never `value`)
+            n_host = 32
+            hm = [frames_np[i % n_frames][0] for i in range(n_host)]
+            ha = [frames_np[i % n_frames][1] for i in range(n_host)]
+            ho = [np.zeros((H, W), np.uint8) for _ in range(n_host)]
+            eng.reset_stream()
+            eng.depth_from_additional_batch(hm[:8], ha[:8], prec, max_steps=args.d_max, outs=ho[:8])
+            t1 = time.perf_counter()
+            eng.depth_from_additional_batch(hm, ha, prec, max_steps=args.d_max, outs=ho)
+            t_page = time.perf_counter() - t1
+            pm = [eng.host_array((H, W, 3)) for _ in range(n_host)]
+            pa = [eng.host_array((H, W, 3)) for _ in range(n_host)]
+            po = [eng.host_array((H, W)) for _ in range(n_host)]
+            for f in range(n_host):
+                pm[f][...] = hm[f]
+                pa[f][...] = ha[f]
+            eng.depth_from_additional_batch(pm[:8], pa[:8], prec, max_steps=args.d_max, outs=po[:8])
+            t1 = time.perf_counter()
+            eng.depth_from_additional_batch(pm, pa, prec, max_steps=args.d_max, outs=po)
+            t_pin = time.perf_counter() - t1
+            dev0, _ = eng.depth_from_additional_batch(mains_t[:1], adds_t[:1], prec, max_steps=args.d_max)
+            e2e_ok = all(np.array_equal(ho[f], po[f]) for f in range(n_host)) and \
+                np.array_equal(ho[0], dev0[0].cpu().numpy())
+            out["end_to_end"] = {
+                "value_pageable": round(n_host * W * H / t_page / 1e6, 1),
+                "value_page_locked": round(n_host * W * H / t_pin / 1e6, 1), "unit": "Mpixels/s",
+                "workload": f"{n_host} host-resident 1920x1080 pairs through the pipelined host batch: "
+                            "H2D of both images, kernels, D2H of the depth map (14.5 MB per frame "
+                            "over PCIe)", "matches_device_path": bool(e2e_ok)}
+            del pm, pa, po, hm, ha, ho
+            eng.use_torch_stream()
+            # -- the engine's second mode on the same frames (north_star's literal windowed SAD;
+            # no counterpart in the reference)
+            sworker = EngineStripWorker(eng, prec, mode=MODE_SAD_WINDOW, d_max=args.d_max, win=args.win)
             sharded_depth(sworker, frames, H, W)
             torch.cuda.synchronize()
             eng.kernel_time_enable(True)
@@ -354,11 +568,8 @@ def main():
                 "frames_per_launch": min(n_frames, 64),
                 "hbm_frac": round(ALGO_BYTES_PER_PIXEL * W * H * min(n_frames, 64)
                                   / (sms / max(sl, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)}
-        if args.mode == "ring" and world == 1:
-            # the reference's complete output: depth map + same-size Gaussian resample
+            # -- the reference's complete output: depth map + same-size Gaussian resample
             # (src/depth_image.rs:133-134; image 0.23.14's sampler restated, parity unpinned)
-            mains_t, adds_t = [f[0] for f in frames], [f[1] for f in frames]
-            outs_t = [torch.empty((H, W), dtype=torch.uint8, device=dev) for _ in frames]
             eng.depth_from_additional_batch(mains_t, adds_t, prec, max_steps=args.d_max,
                                             gaussian_tail=True, outs=outs_t, asynchronous=True)
             torch.cuda.synchronize()
@@ -371,10 +582,9 @@ def main():
             out["with_gaussian_tail"] = {
                 "value": round(px_step / gdt / 1e6, 1), "unit": "Mpixels/s",
                 "workload": "same frames, depth map + same-size Gaussian resample, one stream"}
-        if args.mode == "ring" and world == 1:
-            # README's second half on the depth maps of the last step (Readme.md:18-24):
+            # -- README's second half on the depth maps of the last step (Readme.md:18-24):
             # select_foreground = histogram + depth_split(2) + slice, three launches for all
-            # frames; 1 B read twice + 1 B written per pixel.  Outside the timed region.
+            # frames; 1 B read twice + 1 B written per pixel
             planes = [depth[f] for f in range(n_frames)]
             dl = eng.plane_list(planes, (1,), "depth")
             ml = eng.plane_list([torch.empty_like(p) for p in planes], (1,), "mask")
@@ -392,8 +602,8 @@ def main():
                 "workload": f"select_foreground (depth_split(2) + slice) on the step's {n_frames} depth maps",
                 "ms": round(fms, 4), "algorithmic_bytes_per_pixel": 3,
                 "hbm_frac": round(3 * px_step / (fms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-        if not args.no_cpu_baseline:
-            base, ref_depth = cpu_baseline(frames_np[0], args)
+        if O is not None:
+            base, ref_depth = cpu_baseline(O, sets_np[last_set][0], args)
             out["cpu_baseline"] = base
             got = depth[0].cpu().numpy()
             if args.mode == "ring":
@@ -407,8 +617,7 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    for e_ in engines:
-        e_.close()
+    eng.close()
 
 
 if __name__ == "__main__":

@@ -40,16 +40,18 @@ def _hash01(ix: np.ndarray, iy: np.ndarray, key: int) -> np.ndarray:
 
 
 def _value_noise(w: int, h: int, cell: float, key: int) -> np.ndarray:
-    ys, xs = np.mgrid[0:h, 0:w]
-    fx, fy = xs / cell, ys / cell
+    # lattice coordinates and blend weights depend on the column resp. the row only, and the hash
+    # on the lattice point only: work on 1-D axes and a small lattice table, then broadcast (the
+    # same float64 operations per pixel as the per-pixel formulation, a fraction of the work)
+    fx, fy = np.arange(w) / cell, np.arange(h) / cell
     x0, y0 = np.floor(fx).astype(np.int64), np.floor(fy).astype(np.int64)
     tx, ty = fx - x0, fy - y0
-    tx = tx * tx * (3 - 2 * tx)
-    ty = ty * ty * (3 - 2 * ty)
-    v00 = _hash01(x0, y0, key)
-    v10 = _hash01(x0 + 1, y0, key)
-    v01 = _hash01(x0, y0 + 1, key)
-    v11 = _hash01(x0 + 1, y0 + 1, key)
+    tx = (tx * tx * (3 - 2 * tx))[None, :]
+    ty = (ty * ty * (3 - 2 * ty))[:, None]
+    ly, lx = np.mgrid[0:int(y0.max()) + 2, 0:int(x0.max()) + 2]
+    lat = _hash01(lx, ly, key)
+    v00, v10 = lat[np.ix_(y0, x0)], lat[np.ix_(y0, x0 + 1)]
+    v01, v11 = lat[np.ix_(y0 + 1, x0)], lat[np.ix_(y0 + 1, x0 + 1)]
     return (v00 * (1 - tx) + v10 * tx) * (1 - ty) + (v01 * (1 - tx) + v11 * tx) * ty
 
 
