@@ -773,8 +773,12 @@ int stepth_depth_from_additional(stepth_engine *e, const stepth_image *main_im,
     TRY(check_image(e, main_im, "main", 3, 4));
     TRY(check_image(e, add_im, "additional", 3, 3));
     TRY(check_image(e, depth_im, "depth", 1, 1));
-    const stepth_params p = *pp;
+    stepth_params p = *pp;
     const uint32_t W = main_im->width, H = main_im->height;
+    // a tile larger than the image is the whole image: keeps the 32-bit tile arithmetic below
+    // (strip reach, tile counts) from wrapping
+    p.tile_w = std::min(p.tile_w, W);
+    p.tile_h = std::min(p.tile_h, H);
     // DepthImage::load_depth, src/depth_image.rs:37-49
     if (depth_im->width != W || depth_im->height != H)
         return fail(e, STEPTH_ERR_SIZE_MISMATCH, "Sizes don't match: depth %ux%u vs image %ux%u",
@@ -995,14 +999,17 @@ int stepth_depth_from_additional(stepth_engine *e, const stepth_image *main_im,
                 // 2ty-1..2ty, all of which have middle (tx,ty)
                 ra.ntx = (W >> 1) + 1u;
                 ra.ty0 = (row0 + 1u) >> 1;
-                ra.n_slots = rows ? ra.ntx * ((row1 >> 1) - ra.ty0 + 1u) * 4u : 0u;
+                uint64_t n_slots = rows ? (uint64_t)ra.ntx * ((row1 >> 1) - ra.ty0 + 1u) * 4u : 0u;
                 ra.rp = rp;
                 if (rp.block) {
                     // owned blocks b = rem, rem+mod, ... with b*block < H
                     const uint32_t nb_all = (H + rp.block - 1u) / rp.block;
                     const uint32_t nb = nb_all > rp.rem ? (nb_all - rp.rem + rp.mod - 1u) / rp.mod : 0u;
-                    ra.n_slots = rows ? ra.ntx * nb * (rp.block / 2u + 1u) * 4u : 0u;
+                    n_slots = rows ? (uint64_t)ra.ntx * nb * (rp.block / 2u + 1u) * 4u : 0u;
                 }
+                if (n_slots > 0xFFFFFFFFull && !use_tile)
+                    return fail(e, STEPTH_ERR_BAD_ARG, "%ux%u pixels: too many query slots for one call", W, rows);
+                ra.n_slots = (uint32_t)std::min<uint64_t>(n_slots, 0xFFFFFFFFull);
                 qmode = 0;
             } else {
                 TRY(reserve(e, e->queries, (size_t)std::max(ra.n, 1u) * sizeof(Query)));
@@ -1428,13 +1435,26 @@ static int batch_host(stepth_engine *e, uint32_t n_frames, const stepth_image *m
     const uint32_t n_chunks = (uint32_t)chunks.size();
     std::vector<stepth_image> dm(chunk), da(chunk), dd(chunk);
 
-    auto download = [&](uint32_t k) -> int { // chunk k's depth maps -> caller memory
+    // rows the call computes: only those go back to the caller (the staging buffers hold
+    // nothing meaningful elsewhere); with an interleaved row pattern the other ranks' rows of
+    // the strip travel up first, so that they come back unchanged
+    uint32_t row0 = p.row_begin, row1 = p.row_end;
+    if (row0 == 0 && row1 == 0)
+        row1 = H;
+    if (row0 >= row1 || row1 > H)
+        return fail(e, STEPTH_ERR_BAD_ARG, "row strip [%u,%u) outside 0..%u", row0, row1, H);
+    const bool pattern = p.row_block != 0;
+
+    auto download = [&](uint32_t k) -> int { // chunk k's depth rows -> caller memory
         const uint32_t s = k & 1u, f0 = chunks[k].first, nf = chunks[k].second;
         HIP_TRY(e, hipStreamWaitEvent(e->copy_out, e->ev_compute[s], 0));
         for (uint32_t f = 0; f < nf; ++f)
-            HIP_TRY(e, hipMemcpy2DAsync(const_cast<void *>(depths[f0 + f].data), depths[f0 + f].stride,
-                                        static_cast<uint8_t *>(e->pipe_out[s].p) + obytes * f, opitch, W, H,
-                                        hipMemcpyDeviceToHost, e->copy_out));
+            HIP_TRY(e, hipMemcpy2DAsync(static_cast<uint8_t *>(const_cast<void *>(depths[f0 + f].data)) +
+                                            (size_t)row0 * depths[f0 + f].stride,
+                                        depths[f0 + f].stride,
+                                        static_cast<uint8_t *>(e->pipe_out[s].p) + obytes * f +
+                                            (size_t)row0 * opitch,
+                                        opitch, W, row1 - row0, hipMemcpyDeviceToHost, e->copy_out));
         HIP_TRY(e, hipEventRecord(e->ev_out[s], e->copy_out));
         return STEPTH_OK;
     };
@@ -1444,6 +1464,8 @@ static int batch_host(stepth_engine *e, uint32_t n_frames, const stepth_image *m
         if (k >= 2) { // slot s: inputs consumed by chunk k-2's kernels, outputs by its download
             HIP_TRY(e, hipStreamWaitEvent(e->copy_in, e->ev_compute[s], 0));
             HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_out[s], 0));
+            if (pattern)
+                HIP_TRY(e, hipStreamWaitEvent(e->copy_in, e->ev_out[s], 0));
         }
         for (uint32_t f = 0; f < nf; ++f) {
             uint8_t *m = static_cast<uint8_t *>(e->pipe_main[s].p) + mbytes * f;
@@ -1456,6 +1478,14 @@ static int batch_host(stepth_engine *e, uint32_t n_frames, const stepth_image *m
             da[f] = stepth_image{a, Wa, Ha, 3, STEPTH_MEM_DEVICE, apitch};
             dd[f] = stepth_image{static_cast<uint8_t *>(e->pipe_out[s].p) + obytes * f, W, H, 1,
                                  STEPTH_MEM_DEVICE, opitch};
+            if (pattern)
+                HIP_TRY(e, hipMemcpy2DAsync(static_cast<uint8_t *>(e->pipe_out[s].p) + obytes * f +
+                                                (size_t)row0 * opitch,
+                                            opitch,
+                                            static_cast<const uint8_t *>(depths[f0 + f].data) +
+                                                (size_t)row0 * depths[f0 + f].stride,
+                                            depths[f0 + f].stride, W, row1 - row0, hipMemcpyHostToDevice,
+                                            e->copy_in));
         }
         HIP_TRY(e, hipEventRecord(e->ev_in[s], e->copy_in));
         HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_in[s], 0));

@@ -138,15 +138,35 @@ class Engine:
 
     def set_stream(self, hip_stream: int):
         """Run on this hipStream_t handle (0 = HIP's default stream)."""
+        if getattr(self, "_bound", None) != hip_stream:
+            self._bound = None  # an explicit choice; _follow() rebinds when torch's stream differs
         self._check(self._lib.stepth_engine_set_stream(self._h, hip_stream or None))
 
     def reset_stream(self):
         """Back to the engine's own non-blocking stream."""
+        self._bound = None
         self._check(self._lib.stepth_engine_reset_stream(self._h))
 
     def use_torch_stream(self):
         import torch
-        self.set_stream(torch.cuda.current_stream().cuda_stream)
+        self._bound = torch.cuda.current_stream().cuda_stream
+        self.set_stream(self._bound)
+
+    def _follow(self, *args):
+        """Calls whose arguments are CUDA tensors run on torch's CURRENT stream: whatever
+        produced the tensors (fills, earlier kernels, collectives) is ordered before the
+        engine's kernels and whatever consumes the results after them.  The engine's own
+        non-blocking stream serves numpy (host-memory) calls, which synchronise themselves."""
+        for a in args:
+            if isinstance(a, (list, tuple)):
+                a = a[0] if a else None
+            if a is not None and _is_tensor(a) and a.is_cuda:
+                import torch
+                cur = torch.cuda.current_stream(a.device).cuda_stream
+                if getattr(self, "_bound", None) != cur:
+                    self._bound = cur
+                    self.set_stream(cur)  # (syncs the stream used before)
+                return
 
     def sync(self):
         self._check(self._lib.stepth_engine_sync(self._h))
@@ -165,6 +185,7 @@ class Engine:
         numpy in -> numpy out (synchronous).  torch CUDA tensors in -> tensor out; with
         asynchronous=True nothing is synchronised and `max_out` must be a CUDA int32/uint32
         tensor (or None)."""
+        self._follow(main)
         mi, k1 = _describe(main, (3, 4), "main")
         ai, k2 = _describe(additional, (3,), "additional")
         dev = _is_tensor(main)
@@ -219,6 +240,7 @@ class Engine:
         """stepth_adaptive_groups: the stand-in for disage::open::rgb_discrete (own design,
         parity unpinned).  numpy image -> GROUP_DTYPE array; CUDA tensor -> uint8 CUDA tensor
         [n, 20] (pass either as `groups=` to depth_from_additional).  Order is arbitrary."""
+        self._follow(main)
         mi, _k = _describe(main, (3, 4), "main")
         prec = _u8x3(precision)
         n = C.c_size_t(0)
@@ -248,6 +270,7 @@ class Engine:
         from host_array() copy fastest).  Returns (outs, max): `outs` a list of [H,W] tensors
         / arrays; max a list of ints, or None with asynchronous=True (then `max_out` must be a
         CUDA int32 tensor with one element per frame, or None)."""
+        self._follow(mains)
         n = len(mains)
         if n == 0 or len(additionals) != n:
             raise ValueError("mains and additionals must be equally long, non-empty lists")
@@ -302,6 +325,7 @@ class Engine:
         """stepth_normalise_rows[_pattern], in place.  max_value: int (host) or CUDA tensor
         (device).  With `row_pattern` = (row_block, row_mod, row_rem) only the owned rows of
         the view, whose row 0 is image row `first_row`, are touched."""
+        self._follow(rows)
         ri, _k = _describe(rows, (1,), "rows")
         flags = L.FLAG_ASYNC if asynchronous else 0
         rb, rm, rr = row_pattern if row_pattern is not None else (0, 1, 0)
@@ -322,6 +346,7 @@ class Engine:
                              row_pattern: Optional[Tuple[int, int, int]] = None):
         """stepth_normalise_rows_batch: PASS 2 on equally shaped CUDA views in one launch;
         `max_tensor` holds one int32 per view."""
+        self._follow(rows_list)
         n = len(rows_list)
         ri = (L.Image * n)()
         keep = []
@@ -335,6 +360,7 @@ class Engine:
 
     def gaussian_same_size(self, src, out=None, asynchronous: bool = False):
         """stepth_gaussian_same_size: the reference's `.resize(w, h, Gaussian)` tail."""
+        self._follow(src)
         si, _k1 = _describe(src, (1,), "src")
         if out is None:
             if _is_tensor(src):
@@ -350,6 +376,7 @@ class Engine:
     # ---- consumers of a finished depth map (reference src/depth_image.rs:162-247) ---------
     def invert_depth(self, depth, asynchronous: bool = False):
         """stepth_invert_depth: `depth` (numpy [H,W] or CUDA tensor) becomes 255 - depth in place."""
+        self._follow(depth)
         di, _k = _describe(depth, (1,), "depth")
         self._check(self._lib.stepth_invert_depth(self._h, C.byref(di),
                                                   L.FLAG_ASYNC if asynchronous else 0))
@@ -357,6 +384,7 @@ class Engine:
 
     def depth_split(self, depth, zones: int):
         """stepth_depth_split -> [(lo, hi), ...] in centroid order; [(None, None)] if zones < 2."""
+        self._follow(depth)
         di, _k = _describe(depth, (1,), "depth")
         out = (L.Zone * 256)()
         n = C.c_uint32(0)
@@ -368,6 +396,7 @@ class Engine:
     def depth_histogram(self, depth, out=None, asynchronous: bool = False):
         """stepth_depth_histogram -> 256 counts (int32 CUDA tensor for a CUDA plane, else a
         numpy uint32 array): the per-rank half of depth_split for row-sharded depth maps."""
+        self._follow(depth)
         di, _k = _describe(depth, (1,), "depth")
         if _is_tensor(depth):
             import torch
@@ -403,6 +432,7 @@ class Engine:
 
     def slice(self, depth, from_=None, to=None, out=None, asynchronous: bool = False):
         """stepth_slice -> mask [H,W] u8 (255 inside [from, to], 0 outside)."""
+        self._follow(depth)
         di, _k1 = _describe(depth, (1,), "depth")
         if out is None:
             if _is_tensor(depth):
@@ -418,6 +448,7 @@ class Engine:
 
     def select_foreground(self, depth, out=None):
         """stepth_select_foreground -> (mask, (from, to))."""
+        self._follow(depth)
         di, _k1 = _describe(depth, (1,), "depth")
         if out is None:
             if _is_tensor(depth):
@@ -443,6 +474,7 @@ class Engine:
 
         -> (masks, zones, statuses); zones[f] is (from, to) or None when frame f's split
         failed (its mask is then left as it was).  Asynchronous calls return (masks, None, None)."""
+        self._follow(depths.tensors if isinstance(depths, PlaneList) else depths)
         import torch
         if not isinstance(depths, PlaneList):
             depths = PlaneList(depths, (1,), "depth")
@@ -468,6 +500,7 @@ class Engine:
 
     def apply_mask(self, rgba, mask, asynchronous: bool = False):
         """stepth_apply_mask: RGBA pixels with mask == 0 become [0,0,0,0], in place."""
+        self._follow(rgba)
         ri, _k1 = _describe(rgba, (4,), "rgba")
         mi, _k2 = _describe(mask, (1,), "mask")
         self._check(self._lib.stepth_apply_mask(self._h, C.byref(ri), C.byref(mi),

@@ -43,7 +43,8 @@ def depth_from_files(pairs: Iterable[Tuple[str, str]], precision: Sequence[int],
                      ) -> Iterator[Tuple[np.ndarray, int]]:
     """Yields (depth [H,W] u8, max) for every (main path, additional path) pair, in order.
 
-    All pairs of a chunk must have one size (a chunk is one batched engine call); files that
+    Within a chunk (one batched engine call) all main images must have one size and all
+    additional images one size (the additional size may differ from the main size); files that
     cannot be decoded raise InvalidInput("Failed to open image") like the reference
     (src/depth_image.rs:82-87); a pair whose distances are all zero raises MaxZeroError from
     the chunk it is in."""
@@ -78,9 +79,11 @@ def depth_from_files(pairs: Iterable[Tuple[str, str]], precision: Sequence[int],
                 nxt = start(k + 1, pool)  # decodes while the GPU works on this chunk
             mains = [m for m, _ in decoded]
             adds = [a for _, a in decoded]
-            shapes = {m.shape for m in mains} | {a.shape for a in adds}
-            if len(shapes) != 1:
-                raise InvalidInput("Sizes don't match")
+            # one batched engine call per chunk: all main images of one size, all additional
+            # images of one size -- the two sizes may differ from each other, like in the
+            # reference (src/depth_image.rs:91-100 never compares them)
+            if len({m.shape for m in mains}) != 1 or len({a.shape for a in adds}) != 1:
+                raise InvalidInput("images of one chunk differ in size")
             outs, mx = eng.depth_from_additional_batch(mains, adds, precision, max_steps=max_steps,
                                                        gaussian_tail=gaussian_tail)
             for d, v in zip(outs, mx):

@@ -666,13 +666,26 @@ def test_host_batch_pipeline_matches_oracle(engine, oracle):
     outs, mx = engine.depth_from_additional_batch(pm, pa, [30, 30, 30], max_steps=40, outs=po)
     for f in range(len(mains)):
         assert mx[f] == want[f]["max"] and np.array_equal(po[f], want[f]["depth"]), f
-    # raw-only strips through the same pipeline
+    # raw-only strips through the same pipeline: only the strip's rows come back, the caller's
+    # other rows stay as they were
+    outs = [np.full((120, 200), 99, np.uint8) for _ in range(3)]
     outs, mx = engine.depth_from_additional_batch(mains[:3], adds[:3], [30, 30, 30], max_steps=40,
-                                                  rows=(30, 91), raw_only=True)
+                                                  rows=(30, 91), raw_only=True, outs=outs)
     for f in range(3):
         raw = oracle.match_groups(oracle.uniform_groups(mains[f], 1, 1), adds[f], 40,
                                   [30, 30, 30])["raw"].reshape(120, 200)
         assert np.array_equal(outs[f][30:91], raw[30:91]) and mx[f] == int(raw[30:91].max())
+        assert (outs[f][:30] == 99).all() and (outs[f][91:] == 99).all()
+    # interleaved row blocks on host memory: the rows of the other ranks come back unchanged
+    outs = [np.full((120, 200), 77, np.uint8) for _ in range(3)]
+    outs, mx = engine.depth_from_additional_batch(mains[:3], adds[:3], [30, 30, 30], max_steps=40,
+                                                  rows=(0, 120), row_pattern=(8, 3, 1), raw_only=True,
+                                                  outs=outs)
+    own = ((np.arange(120) // 8) % 3) == 1
+    for f in range(3):
+        raw = oracle.match_groups(oracle.uniform_groups(mains[f], 1, 1), adds[f], 40,
+                                  [30, 30, 30])["raw"].reshape(120, 200)
+        assert np.array_equal(outs[f][own], raw[own]) and (outs[f][~own] == 77).all()
     # mixing host and device memory is refused
     import torch
     with pytest.raises(Exception):

@@ -56,6 +56,65 @@ def test_rejected_hypotheses_stay_rejected(asset):
     assert r < 0.6
 
 
+@pytest.fixture(scope="module")
+def variants(tmp_path_factory, asset):
+    """normalised depth maps of the asset pair under alternative readings of disage's
+    PixelOpps::{substract,lt} (source absent; call site src/helpers.rs:35), from
+    tests/tools/predicate_variants.c -- a literal ring scan with the predicate swapped"""
+    import ctypes as C
+    import os
+    import subprocess
+    from conftest import ROOT
+    out = str(tmp_path_factory.mktemp("pv") / "predicate_variants.so")
+    subprocess.run(["gcc", "-O2", "-fopenmp", "-shared", "-fPIC",
+                    os.path.join(ROOT, "tests", "tools", "predicate_variants.c"), "-o", out, "-lm"],
+                   check=True)
+    lib = C.CDLL(out)
+    lib.variant_raw.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    main = np.ascontiguousarray(asset["main"][..., :3])
+    add = np.ascontiguousarray(asset["additional"][..., :3])
+    ref = asset["depth"].astype(np.float64)
+    res = {}
+    for v in range(5):
+        raw = np.zeros(main.shape[:2], np.uint8)
+        p = (C.c_uint8 * 3)(36, 36, 36)
+        lib.variant_raw(main.ctypes.data, main.shape[1], main.shape[0], add.ctypes.data, add.shape[1],
+                        add.shape[0], C.cast(p, C.c_void_p), 255, v, raw.ctypes.data)
+        d = (raw.astype(np.uint32) * 255 // max(int(raw.max()), 1)).astype(np.float64)
+        res[v] = {"raw": raw, "r": np.corrcoef(d.ravel(), ref.ravel())[0, 1],
+                  "mae": np.abs(d - ref).mean()}
+    return res
+
+
+def test_pinned_predicate_is_the_literal_scan(result, variants):
+    """variant 0 of the helper (|v-w| < p on all channels) is the oracle, byte for byte"""
+    assert np.array_equal(variants[0]["raw"], result["raw"])
+    assert abs(variants[0]["r"] - 0.9811) < 5e-4 and abs(variants[0]["mae"] - 1.222) < 5e-3
+
+
+@pytest.mark.parametrize("variant,name,r_measured", [
+    (1, "saturating subtraction instead of |v-w|", 0.9505),
+    (2, "any channel below precision instead of all", 0.6577),
+    (3, "channel sum below the summed precision", 0.9106),
+])
+def test_rejected_predicates_fit_depth_jpg_worse(variants, variant, name, r_measured):
+    """the three other readings of substract/lt reproduce assets/depth.jpg
+    clearly worse than the pinned one (r 0.9811, MAE 1.222)"""
+    v, ref = variants[variant], variants[0]
+    assert abs(v["r"] - r_measured) < 2e-3, (name, v["r"])
+    assert v["r"] < ref["r"] - 0.025 and v["mae"] > ref["mae"] + 1.0, name
+
+
+def test_strict_less_than_is_weakly_preferred_over_less_or_equal(variants):
+    """`lt` read as <= : r 0.9796 / MAE 1.314 against r 0.9811 / MAE 1.222 for strict <.  The
+    asset prefers the strict reading, but only by a JPEG-noise-sized margin: `<` is pinned by
+    the method's name (`lt`, src/helpers.rs:35) and merely not contradicted by the asset."""
+    lt, le = variants[0], variants[4]
+    assert lt["r"] > le["r"] and lt["mae"] < le["mae"]
+    assert lt["r"] - le["r"] < 0.005  # ... weakly: do not read more into it
+
+
 def test_gaussian_tail_improves_the_fit(result, oracle, asset):
     """src/depth_image.rs:133-134: the same-size Gaussian resample (image 0.23.14's sampler
     restated; PARITY UNPINNED).  With it the oracle matches depth.jpg more closely, which is
