@@ -403,7 +403,11 @@ def main():
                 and os.path.exists(TRAFFIC_FILE):
             prof = json.load(open(TRAFFIC_FILE))
             per_launch = prof.get("dominant_kernel_traffic_bytes_per_launch_corrected")
-            if per_launch and prof.get("frames_per_launch") and DOMINANT_KERNEL in prof.get("dominant_kernel", ""):
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from profile_summaries import kernel_source_sha16
+            # only while the kernels are the ones that were profiled (else null: re-profile)
+            if per_launch and prof.get("frames_per_launch") and DOMINANT_KERNEL in prof.get("dominant_kernel", "") \
+                    and prof.get("kernel_source_sha16") == kernel_source_sha16():
                 traffic = int(per_launch * frames_per_launch / prof["frames_per_launch"])
         n_slots = max(1, args.streams)
         out = {

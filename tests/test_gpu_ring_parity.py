@@ -511,7 +511,22 @@ def test_gaussian_tail_flag_and_device_path(engine, oracle):
         engine.depth_from_additional(l, r, P36, gaussian_tail=True, rows=(0, 64))
 
 
-def test_full_size_properties_1080p(engine):
+def _sampled_raw_equals_oracle(oracle, raw, main, add, prec, max_steps, n=20000, seed=3):
+    """`raw` (GPU, one group per pixel) against the oracle's match_groups on n random pixels
+    (src/depth_image.rs:112-121): the full-size frames take minutes on the CPU, a sample seconds"""
+    h, w = main.shape[:2]
+    rng = np.random.default_rng(seed)
+    ys, xs = rng.integers(0, h, n), rng.integers(0, w, n)
+    g = np.zeros(n, oracle.GROUP_DTYPE)
+    g["x"], g["y"], g["w"], g["h"] = xs, ys, 1, 1
+    g["value"] = main[ys, xs, :3]
+    ref = oracle.match_groups(g, add, max_steps, prec)["raw"]
+    bad = np.flatnonzero(ref != raw[ys, xs])
+    assert len(bad) == 0, f"{len(bad)} of {n} sampled pixels differ, first (x={xs[bad[0]]}, y={ys[bad[0]]}): " \
+                          f"{raw[ys[bad[0]], xs[bad[0]]]} vs oracle {ref[bad[0]]}"
+
+
+def test_full_size_properties_1080p(engine, oracle):
     """BASELINE full size (1920x1080, d_max=128 -> max_steps) without the oracle: size-
     independent properties -- strips compose, idempotence, max/normalise consistency,
     ring-0 pixels are zero, every raw distance is reachable within max_steps."""
@@ -519,6 +534,9 @@ def test_full_size_properties_1080p(engine):
     from stepth_amd import synth
     l, r, _ = synth.stereo_pair(1920, 1080, 128, seed=0x5EED)
     raw, mx = engine.depth_from_additional(l, r, P36, max_steps=128, raw_only=True)
+    _sampled_raw_equals_oracle(oracle, raw, l, r, P36, 128)
+    raw64, _ = engine.depth_from_additional(l, r, P36, max_steps=64, raw_only=True)  # config 2
+    _sampled_raw_equals_oracle(oracle, raw64, l, r, P36, 64, seed=4)
     depth, mx2 = engine.depth_from_additional(l, r, P36, max_steps=128)
     depth_b, _ = engine.depth_from_additional(l, r, P36, max_steps=128)
     np.testing.assert_array_equal(depth, depth_b)  # deterministic
@@ -551,13 +569,15 @@ def _big_frame(w, h):
 
 
 @pytest.mark.parametrize("w,h,ms", [(3840, 2160, 128), (7680, 4320, 255)])
-def test_full_size_properties_4k_8k(engine, w, h, ms):
-    """BASELINE configs 3 and 5 (4K d_max=128, 8K d_max=256 -> max_steps 255) without the
-    oracle: determinism, normalise consistency, ring-0 pixels zero, strips (as dealt to 8
-    ranks) compose to the full frame, the search never reports a distance beyond its reach"""
+def test_full_size_properties_4k_8k(engine, oracle, w, h, ms):
+    """BASELINE configs 3 and 5 (4K d_max=128, 8K d_max=256 -> max_steps 255): 20 000 sampled
+    pixels against the oracle, plus size-independent properties of the whole frame --
+    determinism, normalise consistency, ring-0 pixels zero, strips (as dealt to 8 ranks) compose
+    to the full frame, the search never reports a distance beyond its reach"""
     from stepth_amd.sharding import strip_bounds
     l, r = _big_frame(w, h)
     raw, mx = engine.depth_from_additional(l, r, P36, max_steps=ms, raw_only=True)
+    _sampled_raw_equals_oracle(oracle, raw, l, r, P36, ms)
     depth, mx2 = engine.depth_from_additional(l, r, P36, max_steps=ms)
     assert mx == mx2 == int(raw.max()) and mx > 0
     reach = int(np.floor(np.hypot(ms - 1, ms - 1)))
@@ -823,3 +843,30 @@ def test_batch_rgba_mains_unequal_additional_and_per_channel_precision(engine, o
         ref = refs[i % 7]
         if ref["status"] == 0:
             assert mx[i] == ref["max"] and np.array_equal(outs[i].cpu().numpy(), ref["depth"]), i
+
+
+def test_64_frame_1080p_device_batch_equals_per_frame_calls(engine, oracle):
+    """BASELINE config 4's per-node workload: 64 x 1920x1080 frames through ONE batched call
+    (one set of launches) == 64 single-frame calls, and sampled pixels of two of them == oracle"""
+    import torch
+    from stepth_amd import synth
+    base = [synth.stereo_pair(1920, 1080, 128, seed=0x5EED + i)[:2] for i in range(2)]
+    fl = [lambda a: a, lambda a: a[:, ::-1], lambda a: a[::-1], lambda a: a[::-1, ::-1]]
+    frames = []
+    for i in range(64):
+        l, r = base[i % 2]
+        f = fl[(i // 2) % 4]
+        # beyond the 8 distinct flips: shift the additional image by a few columns, so that all
+        # 64 frames differ
+        k = i // 8
+        frames.append((np.ascontiguousarray(f(l)), np.ascontiguousarray(np.roll(f(r), k, axis=1))))
+    mains = [torch.from_numpy(l).cuda() for l, _ in frames]
+    adds = [torch.from_numpy(r).cuda() for _, r in frames]
+    outs, mx = engine.depth_from_additional_batch(mains, adds, P36, max_steps=128, raw_only=True)
+    torch.cuda.synchronize()
+    for i in range(64):
+        one, m1 = engine.depth_from_additional(mains[i], adds[i], P36, max_steps=128, raw_only=True)
+        assert m1 == mx[i] and torch.equal(one, outs[i]), i
+    for i in (5, 62):
+        _sampled_raw_equals_oracle(oracle, outs[i].cpu().numpy(), frames[i][0], frames[i][1], P36, 128,
+                                   n=8000, seed=i)

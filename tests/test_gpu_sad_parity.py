@@ -109,3 +109,29 @@ def test_sad_batch_equals_frame_by_frame(engine, oracle):
         assert np.array_equal(outs[f], oracle.sad_rows(hl[f], hr[f], 24, 9, [4, 4, 4])), f
     with pytest.raises(Exception):  # interleaved patterns are a ring-mode feature
         engine.depth_from_additional_batch(dl, dr, [4, 4, 4], row_pattern=(2, 2, 0), **kw)
+
+
+@pytest.mark.parametrize("w,h,d_max,win", [(1920, 1080, 64, 5), (3840, 2160, 128, 5), (7680, 4320, 256, 9)])
+def test_sad_full_size_band_against_oracle(engine, oracle, w, h, d_max, win):
+    """the SAD mode at BASELINE's full sizes (configs 2, 3, 5): a 16-row band of the full-frame
+    result against oracle.sad_rows (the whole frame would take the CPU minutes), the band as a
+    strip call, and determinism of the full frame"""
+    from stepth_amd import synth
+    l0, r0, _ = synth.stereo_pair(960, 540, min(d_max, 128), seed=0x5AD)
+    def tile(a):
+        row = np.concatenate([a, a[:, ::-1]], axis=1)
+        quad = np.concatenate([row, row[::-1]], axis=0)
+        reps = (-(-h // quad.shape[0]), -(-w // quad.shape[1]), 1)
+        return np.ascontiguousarray(np.tile(quad, reps)[:h, :w])
+    l, r = tile(l0), tile(r0)
+    prec = [4, 4, 4]
+    raw, mx = run_sad(engine, l, r, d_max, win, prec, raw_only=True)
+    raw2, _ = run_sad(engine, l, r, d_max, win, prec, raw_only=True)
+    np.testing.assert_array_equal(raw, raw2)
+    y0 = h // 2 - 8
+    ref = oracle.sad_rows(l, r, d_max, win, prec, y0, y0 + 16)
+    np.testing.assert_array_equal(raw[y0:y0 + 16], ref[y0:y0 + 16])
+    band = np.zeros_like(raw)
+    run_sad(engine, l, r, d_max, win, prec, raw_only=True, rows=(y0, y0 + 16), out=band)
+    np.testing.assert_array_equal(band[y0:y0 + 16], raw[y0:y0 + 16])
+    assert mx == int(raw.max()) and mx < d_max

@@ -1,6 +1,6 @@
 """Multi-rank rehearsal of the sharded flow on the real engine (several ranks sharing the GPUs
 that are there, gloo backend): work-weighted strips + pipelined gather + steps alternating over
-two streams, every frame of every step compared with the single-process result.
+two streams, every frame of every step compared with the oracle.
     python -m torch.distributed.run --nproc-per-node 3 --master-addr 127.0.0.1 tests/tools/rehearse_multirank.py
 """
 import os
@@ -29,8 +29,9 @@ for e, s in zip(engines, streams):
     with torch.cuda.stream(s):
         e.use_torch_stream()
 workers = [EngineStripWorker(e, [36] * 3, max_steps=48, tile=(1, 1), mode=MODE_RING_FIRST_HIT) for e in engines]
-ref_eng = Engine(dev.index)
-want = [ref_eng.depth_from_additional(l, r, [36] * 3, max_steps=48)[0].cpu().numpy() for l, r in frames]
+# expected depth maps: the oracle (the CPU restatement of the reference), not the engine
+from oracle import oracle as O
+want = [O.depth_from_additional(l, r, [36] * 3, 48, (1, 1))["depth"] for l, r in pairs]
 bal = StripBalancer(H, world, align=2, min_rows=8, lag=2)
 pipes = [GatherPipeline(), GatherPipeline()]
 history, bad = [], 0
