@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define STEPTH_ABI_VERSION 2u
+#define STEPTH_ABI_VERSION 3u
 
 typedef struct stepth_engine stepth_engine; /* opaque */
 
@@ -187,7 +187,8 @@ int stepth_adaptive_groups(stepth_engine *engine, const stepth_image *main,
  * small frame or row strip cannot fill the GPU -- the cost of a query varies by two orders of
  * magnitude and one heavy query is a ~100 us critical path -- so callers with several frames
  * in flight (video, row-strip sharding of many frames) should batch them.
- *   - ring mode with uniform 1x1 tiles (one group per pixel), or the windowed-SAD mode
+ *   - ring mode with uniform tiles (1x1 = one group per pixel, the dense search; larger tiles
+ *     take their floor mean colour as value, device memory only), or the windowed-SAD mode
  *     (contiguous row strips only); every frame the same sizes; params (rows, row pattern,
  *     flags) apply to every frame;
  *   - every image in device memory (same strides for every frame), or every image in host
@@ -206,6 +207,29 @@ int stepth_depth_from_additional_batch(stepth_engine *engine, uint32_t n_frames,
                                        const stepth_image *mains, const stepth_image *additionals,
                                        const stepth_params *params, const stepth_image *depths,
                                        uint32_t *max_out);
+
+/*
+ * The reference's real flow for many frames (src/depth_image.rs:104-132): grouping -> match ->
+ * normalise -> paint, each stage ONE set of launches for all frames.
+ *
+ * stepth_adaptive_groups_batch: stepth_adaptive_groups for n_frames device images of one shape;
+ *   groups_out[f] = device memory for `capacity` >= width*height groups of frame f, n_out[f]
+ *   (host) = the number written.  One host synchronisation at the end (the counts).
+ * stepth_depth_from_groups_batch: stepth_depth_from_additional with an explicit group list per
+ *   frame: groups[f] = n_groups[f] stepth_group in DEVICE memory (e.g. straight from
+ *   stepth_adaptive_groups_batch: the groups never leave the device), images in device memory
+ *   of one shape, ring mode, contiguous row strips (params.row_begin/row_end), flags ASYNC /
+ *   RAW_ONLY; max_out as in stepth_depth_from_additional_batch.
+ */
+int stepth_adaptive_groups_batch(stepth_engine *engine, uint32_t n_frames, const stepth_image *mains,
+                                 const uint8_t precision[3], uint32_t min_splits,
+                                 uint32_t max_splits, stepth_group *const *groups_out,
+                                 size_t capacity, size_t *n_out);
+int stepth_depth_from_groups_batch(stepth_engine *engine, uint32_t n_frames,
+                                   const stepth_image *mains, const stepth_image *additionals,
+                                   const stepth_params *params, const stepth_group *const *groups,
+                                   const size_t *n_groups, const stepth_image *depths,
+                                   uint32_t *max_out);
 
 /*
  * Page-locked host memory for image buffers handed to the engine as STEPTH_MEM_HOST (decode

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libstepth_amd.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "stepth_amd.h")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # stepth_status
 OK = 0
@@ -86,6 +86,11 @@ SYMBOLS = {
                                          C.c_void_p, C.c_size_t, C.c_uint32, _P(C.c_size_t)]),
     "stepth_depth_from_additional_batch": (C.c_int, [C.c_void_p, C.c_uint32, _P(Image), _P(Image),
                                                      _P(Params), _P(Image), C.c_void_p]),
+    "stepth_adaptive_groups_batch": (C.c_int, [C.c_void_p, C.c_uint32, _P(Image), C.c_void_p, C.c_uint32,
+                                               C.c_uint32, _P(C.c_void_p), C.c_size_t, _P(C.c_size_t)]),
+    "stepth_depth_from_groups_batch": (C.c_int, [C.c_void_p, C.c_uint32, _P(Image), _P(Image),
+                                                 _P(Params), _P(C.c_void_p), _P(C.c_size_t), _P(Image),
+                                                 C.c_void_p]),
     "stepth_host_alloc": (C.c_int, [_P(C.c_void_p), C.c_size_t]),
     "stepth_host_free": (None, [C.c_void_p]),
     "stepth_normalise_rows": (C.c_int, [C.c_void_p, _P(Image), C.c_void_p, C.c_uint32,

@@ -410,7 +410,7 @@ int ensure_spiral(stepth_engine *e, uint32_t max_steps, uint32_t wa, uint32_t ha
     return STEPTH_OK;
 }
 
-// ra.n = queries per frame; n_frames > 1 only for QMODE 0 (one query per pixel)
+// ra.n = queries per frame (QMODE 1: the largest of ra.nq[f])
 int launch_ring(stepth_engine *e, RingArgs &ra, int qmode, uint32_t n_frames = 1)
 {
     if (ra.n == 0)
@@ -500,7 +500,7 @@ int launch_ring(stepth_engine *e, RingArgs &ra, int qmode, uint32_t n_frames = 1
         ((std::min(ra.max_steps, std::max(ra.wa, ra.ha)) + 6u) >> 3) > kSpiralRings;
     const bool st = e->stats_enabled;
     {
-        const dim3 g0(blocks, qmode == 0 ? n_frames : 1u), b0(256);
+        const dim3 g0(blocks, n_frames), b0(256);
 #define STEPTH_RING0(Q, S, I) hipLaunchKernelGGL((ring0_kernel<Q, S, I>), g0, b0, 0, e->stream, ra)
         if (qmode == 0 && small_launch) {
             if (st) STEPTH_RING0(0, true, kRing0ItersSmall); else STEPTH_RING0(0, false, kRing0ItersSmall);
@@ -962,8 +962,8 @@ int stepth_depth_from_additional(stepth_engine *e, const stepth_image *main_im,
             ra.n = (uint32_t)n_groups;
             TRY(reserve(e, e->queries, (size_t)ra.n * sizeof(Query)));
             PrepArgs pr{};
-            pr.groups = d_groups;
-            pr.n = ra.n;
+            pr.groups[0] = d_groups;
+            pr.n[0] = ra.n;
             pr.row_begin = row0;
             pr.row_end = row1;
             memcpy(pr.prec, p.precision, 3);
@@ -971,6 +971,7 @@ int stepth_depth_from_additional(stepth_engine *e, const stepth_image *main_im,
             hipLaunchKernelGGL(prep_list_kernel, dim3((ra.n + 255) / 256), dim3(256), 0, e->stream, pr);
             HIP_TRY(e, hipGetLastError());
             ra.queries = pr.out;
+            ra.nq[0] = ra.n;
             qmode = 1;
             // groups not in the strip paint nothing; unpainted pixels keep the caller's bytes,
             // so clear the strip first like ImageBuffer::from_pixel(.., Luma([0])) (:20)
@@ -1014,7 +1015,7 @@ int stepth_depth_from_additional(stepth_engine *e, const stepth_image *main_im,
             } else {
                 TRY(reserve(e, e->queries, (size_t)std::max(ra.n, 1u) * sizeof(Query)));
                 PrepArgs pr{};
-                pr.main_px = d_main;
+                pr.main_px[0] = d_main;
                 pr.mstride = ms;
                 pr.mch = main_im->channels;
                 pr.w = W;
@@ -1023,7 +1024,7 @@ int stepth_depth_from_additional(stepth_engine *e, const stepth_image *main_im,
                 pr.tile_h = p.tile_h;
                 pr.gx = gx;
                 pr.gy = gy;
-                pr.n = ra.n;
+                pr.n[0] = ra.n;
                 pr.row_begin = row0;
                 pr.row_end = row1;
                 pr.rp = rp;
@@ -1035,6 +1036,7 @@ int stepth_depth_from_additional(stepth_engine *e, const stepth_image *main_im,
                     HIP_TRY(e, hipGetLastError());
                 }
                 ra.queries = pr.out;
+                ra.nq[0] = ra.n;
                 qmode = 1;
             }
         }
@@ -1050,7 +1052,8 @@ int stepth_depth_from_additional(stepth_engine *e, const stepth_image *main_im,
             TRY(launch_ring(e, ra, qmode));
 
         pa.raw = ra.raw;
-        pa.groups = d_groups;
+        pa.groups_list[0] = d_groups;
+        pa.n_list[0] = ra.n;
         pa.n = ra.n;
         if (rows && ra.n) {
             max_published = async && max_out;
@@ -1201,6 +1204,144 @@ static int batch_sad(stepth_engine *e, uint32_t n_frames, const stepth_image *ma
     return STEPTH_OK;
 }
 
+// PASS 1 + PASS 2 + paint for the prepared-query modes -- uniform tiles larger than 1x1
+// (d_groups == nullptr) or one group list per frame -- for nf <= kMaxBatch device frames in
+// one set of launches (src/depth_image.rs:104-132 for nf images at once).
+static int ring_queries_batch(stepth_engine *e, uint32_t nf, const stepth_image *mains,
+                              const stepth_image *adds, const stepth_params &p, uint32_t row0,
+                              uint32_t row1, RowPattern rp, const void *const *d_groups,
+                              const uint32_t *n_groups, const stepth_image *depths,
+                              uint32_t *max_out, bool &any_zero)
+{
+    const uint32_t W = mains[0].width, H = mains[0].height, rows = row1 - row0;
+    const bool async = p.flags & STEPTH_FLAG_ASYNC, raw_only = p.flags & STEPTH_FLAG_RAW_ONLY;
+    const uint8_t *d_adds[kMaxBatch];
+    for (uint32_t f = 0; f < nf; ++f)
+        d_adds[f] = static_cast<const uint8_t *>(adds[f].data);
+    uint32_t bw = 0, bh = 0, lo = 0, hi = 0xFFFFFFFFu;
+    if (!d_groups && p.max_steps < 0x40000000u) { // rows the tiles' searches can reach
+        const uint32_t reach = p.max_steps ? p.max_steps - 1u : 0u;
+        const uint32_t c_lo = row0 / 2u, c_hi = (row1 + p.tile_h) / 2u;
+        lo = c_lo > reach ? c_lo - reach : 0u;
+        hi = c_hi + reach + 1u;
+    }
+    TRY(pack_additional(e, nf, d_adds, adds[0].stride, adds[0].width, adds[0].height, bw, bh, lo, hi));
+
+    RingArgs ra{};
+    ra.T = (const uint32_t *)e->T.p;
+    ra.BB = (const uint2 *)e->BB.p;
+    ra.SB = (const uint2 *)e->SB.p;
+    ra.sbw = (bw + 7u) / 8u;
+    ra.sbh = (bh + 7u) / 8u;
+    ra.wa = adds[0].width;
+    ra.ha = adds[0].height;
+    ra.bw = bw;
+    ra.bh = bh;
+    ra.max_steps = p.max_steps;
+    memcpy(ra.prec, p.precision, 3);
+    ra.max_word = e->words;
+
+    PrepArgs pr{};
+    pr.row_begin = row0;
+    pr.row_end = row1;
+    pr.rp = rp;
+    memcpy(pr.prec, p.precision, 3);
+    uint32_t gx = 0, n_max = 0;
+    if (d_groups) {
+        for (uint32_t f = 0; f < nf; ++f) {
+            pr.groups[f] = d_groups[f];
+            pr.n[f] = n_groups[f];
+            n_max = std::max(n_max, n_groups[f]);
+        }
+    } else {
+        gx = (W + p.tile_w - 1) / p.tile_w;
+        n_max = gx * ((rows + p.tile_h - 1) / p.tile_h);
+        for (uint32_t f = 0; f < nf; ++f) {
+            pr.main_px[f] = static_cast<const uint8_t *>(mains[f].data);
+            pr.n[f] = n_max;
+        }
+        pr.mstride = mains[0].stride;
+        pr.mch = mains[0].channels;
+        pr.w = W;
+        pr.h = H;
+        pr.tile_w = p.tile_w;
+        pr.tile_h = p.tile_h;
+        pr.gx = gx;
+        pr.gy = (rows + p.tile_h - 1) / p.tile_h;
+    }
+    if (n_max == 0)
+        return STEPTH_OK;
+    pr.q_stride = n_max;
+    TRY(reserve(e, e->queries, (size_t)n_max * nf * sizeof(Query)));
+    pr.out = (Query *)e->queries.p;
+    const dim3 pgrid((n_max + 255) / 256, nf);
+    if (d_groups)
+        hipLaunchKernelGGL(prep_list_kernel, pgrid, dim3(256), 0, e->stream, pr);
+    else
+        hipLaunchKernelGGL(prep_tiles_kernel, pgrid, dim3(256), 0, e->stream, pr);
+    HIP_TRY(e, hipGetLastError());
+    ra.queries = pr.out;
+    ra.q_stride = n_max;
+    for (uint32_t f = 0; f < nf; ++f)
+        ra.nq[f] = pr.n[f];
+    ra.n = n_max;
+    const size_t raw_stride = ((size_t)n_max + 3u) & ~(size_t)3u;
+    TRY(reserve(e, e->raw, raw_stride * nf));
+    ra.raw = static_cast<uint8_t *>(e->raw.p);
+    if (e->stats_enabled) {
+        HIP_TRY(e, hipMemsetAsync(e->stats, 0, 64, e->stream));
+        e->stats_groups = 0;
+        for (uint32_t f = 0; f < nf; ++f)
+            e->stats_groups += pr.n[f];
+    }
+    TRY(launch_ring(e, ra, 1, nf));
+
+    PaintArgs pa{};
+    pa.raw = ra.raw;
+    pa.raw_stride = (uint32_t)raw_stride;
+    pa.max_word = e->words;
+    pa.max_out = (async && max_out) ? max_out : nullptr;
+    pa.identity = raw_only;
+    for (uint32_t f = 0; f < nf; ++f)
+        pa.out[f] = static_cast<uint8_t *>(const_cast<void *>(depths[f].data));
+    pa.ostride = depths[0].stride;
+    pa.w = W;
+    pa.h = H;
+    pa.row_begin = row0;
+    pa.row_end = row1;
+    pa.rp = rp;
+    pa.n = n_max;
+    if (d_groups) {
+        // groups not in the strip paint nothing; unpainted pixels must read 0 like
+        // ImageBuffer::from_pixel(.., Luma([0])) (src/depth_image.rs:20)
+        for (uint32_t f = 0; f < nf; ++f) {
+            pa.groups_list[f] = d_groups[f];
+            pa.n_list[f] = n_groups[f];
+            HIP_TRY(e, hipMemset2DAsync(pa.out[f] + (size_t)row0 * pa.ostride, pa.ostride, 0, W, rows, e->stream));
+        }
+        hipLaunchKernelGGL(paint_list_kernel, dim3((n_max + 3) / 4, nf), dim3(256), 0, e->stream, pa);
+    } else {
+        pa.tile_w = p.tile_w;
+        pa.tile_h = p.tile_h;
+        pa.gx = gx;
+        const size_t total = (size_t)rows * W;
+        hipLaunchKernelGGL(paint_tiles_kernel, dim3((uint32_t)std::min<size_t>((total + 255) / 256, 1024), nf),
+                           dim3(256), 0, e->stream, pa);
+    }
+    HIP_TRY(e, hipGetLastError());
+    if (!async) {
+        uint32_t mx[kMaxBatch];
+        HIP_TRY(e, hipMemcpyAsync(mx, e->words, 4 * nf, hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(e, hipStreamSynchronize(e->stream));
+        for (uint32_t f = 0; f < nf; ++f) {
+            if (max_out)
+                max_out[f] = mx[f];
+            any_zero |= mx[f] == 0;
+        }
+    }
+    return STEPTH_OK;
+}
+
 int stepth_depth_from_additional_batch(stepth_engine *e, uint32_t n_frames,
                                        const stepth_image *mains, const stepth_image *adds,
                                        const stepth_params *pp, const stepth_image *depths,
@@ -1214,10 +1355,11 @@ int stepth_depth_from_additional_batch(stepth_engine *e, uint32_t n_frames,
         return fail(e, STEPTH_ERR_BAD_ARG, "empty batch or null image arrays");
     const stepth_params p = *pp;
     const bool sad = p.mode == STEPTH_MODE_SAD_WINDOW;
-    if (!sad && (p.mode != STEPTH_MODE_RING_FIRST_HIT || p.tile_w != 1 || p.tile_h != 1))
-        return fail(e, STEPTH_ERR_BAD_ARG, "batch: ring mode with 1x1 tiles or SAD mode");
+    if (!sad && (p.mode != STEPTH_MODE_RING_FIRST_HIT || p.tile_w == 0 || p.tile_h == 0))
+        return fail(e, STEPTH_ERR_BAD_ARG, "batch: ring mode with uniform tiles or SAD mode");
+    const bool tiles = !sad && (p.tile_w != 1 || p.tile_h != 1);
     const bool gauss_tail = p.flags & STEPTH_FLAG_GAUSSIAN_TAIL;
-    if (gauss_tail && (sad || (p.flags & STEPTH_FLAG_RAW_ONLY) || p.row_block ||
+    if (gauss_tail && (sad || tiles || (p.flags & STEPTH_FLAG_RAW_ONLY) || p.row_block ||
                        !(p.row_begin == 0 && (p.row_end == 0 || p.row_end == mains[0].height))))
         return fail(e, STEPTH_ERR_BAD_ARG,
                     "STEPTH_FLAG_GAUSSIAN_TAIL needs whole normalised ring-mode frames");
@@ -1235,8 +1377,11 @@ int stepth_depth_from_additional_batch(stepth_engine *e, uint32_t n_frames,
         if (depths[f].width != mains[0].width || depths[f].height != mains[0].height)
             return fail(e, STEPTH_ERR_SIZE_MISMATCH, "Sizes don't match");
     }
-    if (n_host == 3 * n_frames) // every image in host memory: staged and pipelined
+    if (n_host == 3 * n_frames) { // every image in host memory: staged and pipelined
+        if (tiles)
+            return fail(e, STEPTH_ERR_BAD_ARG, "batch: host-memory frames take 1x1 tiles or the SAD mode");
         return batch_host(e, n_frames, mains, adds, p, depths, max_out);
+    }
     for (uint32_t f = 0; f < n_frames; ++f) {
         if (mains[f].memory != STEPTH_MEM_DEVICE || adds[f].memory != STEPTH_MEM_DEVICE ||
             depths[f].memory != STEPTH_MEM_DEVICE)
@@ -1268,6 +1413,27 @@ int stepth_depth_from_additional_batch(stepth_engine *e, uint32_t n_frames,
     bool any_zero = false;
     if (sad)
         return batch_sad(e, n_frames, mains, adds, p, depths, max_out, row0, row1);
+    if (tiles) {
+        // uniform tiles larger than one pixel (value = floor mean colour): prepared queries
+        stepth_params tp = p;
+        tp.tile_w = std::min(tp.tile_w, W);
+        tp.tile_h = std::min(tp.tile_h, H);
+        if (row0 % tp.tile_h != 0 || (row1 % tp.tile_h != 0 && row1 != H))
+            return fail(e, STEPTH_ERR_BAD_ARG, "row strip [%u,%u) not aligned to tile_h %u", row0, row1, tp.tile_h);
+        if (p.row_block && p.row_block % tp.tile_h != 0)
+            return fail(e, STEPTH_ERR_BAD_ARG, "row pattern: row_block must be a multiple of tile_h");
+        const uint64_t cells_t = (uint64_t)((adds[0].width + 7u) / 8u) * ((adds[0].height + 7u) / 8u) * 64u;
+        const uint32_t chunk_t = (uint32_t)std::max<uint64_t>(
+            1, std::min<uint64_t>(kMaxBatch, 0x3FFFFFFFull / std::max<uint64_t>(cells_t, 1)));
+        for (uint32_t f0 = 0; f0 < n_frames; f0 += chunk_t) {
+            const uint32_t nf = std::min<uint32_t>(chunk_t, n_frames - f0);
+            TRY(ring_queries_batch(e, nf, mains + f0, adds + f0, tp, row0, row1, rp, nullptr, nullptr,
+                                   depths + f0, max_out ? max_out + f0 : nullptr, any_zero));
+        }
+        if (!async && any_zero && !raw_only)
+            return fail(e, STEPTH_ERR_MAX_ZERO, "a frame's distances are all 0; its output is all zero");
+        return STEPTH_OK;
+    }
 
     // frames per set of launches: at most kMaxBatch, and few enough that all their cells can be
     // indexed with 32 bits
@@ -1696,6 +1862,7 @@ int stepth_distance_dot_array_batch(stepth_engine *e, const stepth_image *array,
     ra.bh = bh;
     ra.queries = (const Query *)e->queries.p;
     ra.n = (uint32_t)n;
+    ra.nq[0] = (uint32_t)n;
     ra.max_steps = max;
     memcpy(ra.prec, precision, 3);
     ra.raw = (uint8_t *)e->raw.p;

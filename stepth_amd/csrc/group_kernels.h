@@ -29,14 +29,15 @@ struct GroupNode {
 };
 
 struct AdaptiveArgs {
-    const uint8_t *px; // main image, `ch` bytes per pixel
+    const uint8_t *px[kMaxBatch]; // main images (one per frame, blockIdx.y), `ch` bytes per pixel
     size_t stride;
     uint32_t ch, W, H;
     uint32_t prec[3];
     uint32_t min_splits, max_splits, seed_depth; // seed_depth = min(min_splits, max_splits)
-    GroupRec *groups;                            // capacity W*H
-    GroupNode *list[3];                          // node lists of levels d, d+1, d+2 (rotating)
-    uint32_t *counters;                          // [0] groups, [1 + level % 3] list lengths
+    GroupRec *groups[kMaxBatch];                 // capacity W*H each
+    GroupNode *list[3];                          // node lists of levels d, d+1, d+2 (rotating) ...
+    size_t list_stride;                          // ... frame f's at list[k] + f * list_stride
+    uint32_t *counters;                          // per frame 4 words: [0] groups, [1 + level % 3] list lengths
 };
 
 // appends `v` for the lanes with `yes` to an array with length counter `count`: one atomic
@@ -56,8 +57,8 @@ template <typename T> __device__ __forceinline__ void wave_append(bool yes, T *a
 }
 
 // statistics of a rectangle -> leaf? ; writes the group or the two children
-__device__ __forceinline__ void adaptive_visit(const AdaptiveArgs &a, bool live, GroupNode n, uint32_t depth,
-                                               GroupNode *next, uint32_t *next_count)
+__device__ __forceinline__ void adaptive_visit(const AdaptiveArgs &a, uint32_t f, bool live, GroupNode n,
+                                               uint32_t depth, GroupNode *next, uint32_t *next_count)
 {
     bool leaf = false;
     uint32_t sum[3] = {0, 0, 0};
@@ -68,7 +69,7 @@ __device__ __forceinline__ void adaptive_visit(const AdaptiveArgs &a, bool live,
             uint32_t mn[3] = {255, 255, 255}, mx[3] = {0, 0, 0};
             unsigned long long s64[3] = {0, 0, 0};
             for (uint32_t yy = n.y; yy < n.y + n.h; ++yy) {
-                const uint8_t *p = a.px + (size_t)yy * a.stride + (size_t)n.x * a.ch;
+                const uint8_t *p = a.px[f] + (size_t)yy * a.stride + (size_t)n.x * a.ch;
                 for (uint32_t xx = 0; xx < n.w; ++xx, p += a.ch) {
 #pragma unroll
                     for (int k = 0; k < 3; ++k) {
@@ -101,7 +102,7 @@ __device__ __forceinline__ void adaptive_visit(const AdaptiveArgs &a, bool live,
             }
         }
     }
-    wave_append(live && leaf, a.groups, &a.counters[0], g);
+    wave_append(live && leaf, a.groups[f], &a.counters[4u * f], g);
     const bool split = live && !leaf;
     GroupNode c0 = n, c1 = n;
     if (n.w >= n.h) {
@@ -134,6 +135,7 @@ __device__ __forceinline__ void adaptive_visit(const AdaptiveArgs &a, bool live,
 // remaining bits are all zero.
 __global__ __launch_bounds__(256) void adaptive_seed_kernel(AdaptiveArgs a)
 {
+    const uint32_t f = blockIdx.y;
     const uint64_t total = 1ull << a.seed_depth;
     const uint64_t rounds = (total + (uint64_t)gridDim.x * 256 - 1) / ((uint64_t)gridDim.x * 256);
     for (uint64_t r = 0; r < rounds; ++r) { // whole waves stay together for the ballots
@@ -157,7 +159,8 @@ __global__ __launch_bounds__(256) void adaptive_seed_kernel(AdaptiveArgs a)
                 n.h = second ? n.h - h0 : h0;
             }
         }
-        adaptive_visit(a, live, n, depth, a.list[(a.seed_depth + 1) % 3], &a.counters[1 + (a.seed_depth + 1) % 3]);
+        adaptive_visit(a, f, live, n, depth, a.list[(a.seed_depth + 1) % 3] + f * a.list_stride,
+                       &a.counters[4u * f + 1 + (a.seed_depth + 1) % 3]);
     }
 }
 
@@ -166,16 +169,19 @@ __global__ __launch_bounds__(256) void adaptive_seed_kernel(AdaptiveArgs a)
 // level depth + 1 to append to (no launch in between needs it).
 __global__ __launch_bounds__(256) void adaptive_level_kernel(AdaptiveArgs a, uint32_t depth)
 {
-    const uint32_t count = a.counters[1 + depth % 3];
+    const uint32_t f = blockIdx.y;
+    uint32_t *counters = a.counters + 4u * f;
+    const uint32_t count = counters[1 + depth % 3];
     if (blockIdx.x == 0 && threadIdx.x == 0)
-        a.counters[1 + (depth + 2) % 3] = 0;
+        counters[1 + (depth + 2) % 3] = 0;
     const uint32_t rounds = (count + gridDim.x * 256 - 1) / (gridDim.x * 256);
-    const GroupNode *in = a.list[depth % 3];
+    const GroupNode *in = a.list[depth % 3] + f * a.list_stride;
     for (uint32_t r = 0; r < rounds; ++r) {
         const uint32_t i = (r * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
         const bool live = i < count;
         const GroupNode n = live ? in[i] : GroupNode{0, 0, 1, 1};
-        adaptive_visit(a, live, n, depth, a.list[(depth + 1) % 3], &a.counters[1 + (depth + 1) % 3]);
+        adaptive_visit(a, f, live, n, depth, a.list[(depth + 1) % 3] + f * a.list_stride,
+                       &counters[1 + (depth + 1) % 3]);
     }
 }
 

@@ -145,14 +145,15 @@ struct Query {
 };
 
 struct PrepArgs {
-    // uniform tiles from the main image
-    const uint8_t *main_px;
+    // uniform tiles from the main image (one image per frame, blockIdx.y)
+    const uint8_t *main_px[kMaxBatch];
     size_t mstride;
     uint32_t mch, w, h;
     uint32_t tile_w, tile_h, gx, gy;
-    // or an explicit list
-    const void *groups; // stepth_group[n]
-    uint32_t n;
+    // or an explicit list per frame
+    const void *groups[kMaxBatch]; // stepth_group[n[f]]
+    uint32_t n[kMaxBatch];         // queries of frame f (tiles: the same for every frame)
+    uint32_t q_stride;             // queries between the frames' arrays in `out`
     uint32_t row_begin, row_end;
     RowPattern rp;
     uint8_t prec[3];
@@ -169,8 +170,8 @@ struct GroupRec { // == stepth_group
 // disage's MeanBrightnessHasher grouping, src/depth_image.rs:104-109; parity unpinned)
 __global__ __launch_bounds__(256) void prep_tiles_kernel(PrepArgs a)
 {
-    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= a.n)
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x, f = blockIdx.y;
+    if (g >= a.n[f])
         return;
     const uint32_t gy0 = a.row_begin / a.tile_h; // strips are tile-aligned (checked on host)
     const uint32_t tyi = gy0 + g / a.gx, txi = g % a.gx;
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(256) void prep_tiles_kernel(PrepArgs a)
     const uint32_t w = min(a.tile_w, a.w - x), h = min(a.tile_h, a.h - y);
     uint32_t sum[3] = {0, 0, 0};
     for (uint32_t yy = y; yy < y + h; ++yy) {
-        const uint8_t *row = a.main_px + (size_t)yy * a.mstride;
+        const uint8_t *row = a.main_px[f] + (size_t)yy * a.mstride;
         for (uint32_t xx = x; xx < x + w; ++xx) {
             const uint8_t *p = row + (size_t)xx * a.mch;
             sum[0] += p[0];
@@ -195,15 +196,15 @@ __global__ __launch_bounds__(256) void prep_tiles_kernel(PrepArgs a)
     if (!a.rp.owns(y))
         q.cx = q.cy = ~0u; // another rank's tile row
     make_box(v, a.prec, q.lo, q.hi);
-    a.out[g] = q;
+    a.out[(size_t)f * a.q_stride + g] = q;
 }
 
 __global__ __launch_bounds__(256) void prep_list_kernel(PrepArgs a)
 {
-    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= a.n)
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x, f = blockIdx.y;
+    if (g >= a.n[f])
         return;
-    const GroupRec r = reinterpret_cast<const GroupRec *>(a.groups)[g];
+    const GroupRec r = reinterpret_cast<const GroupRec *>(a.groups[f])[g];
     Query q;
     if (r.y >= a.row_begin && r.y < a.row_end) {
         q.cx = (r.x + r.w) / 2u; // u32 arithmetic like the reference (wraps on overflow)
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(256) void prep_list_kernel(PrepArgs a)
         q.cx = q.cy = ~0u;
     }
     make_box(r.value, a.prec, q.lo, q.hi);
-    a.out[g] = q;
+    a.out[(size_t)f * a.q_stride + g] = q;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -260,9 +261,11 @@ struct RingArgs {
     uint32_t mch, w, row0, row1;
     uint32_t ntx, ty0, n_slots; // 2x2 tiles of the strip: columns, first tile row, slots
     RowPattern rp;              // with a pattern: slots walk the owned row blocks only
-    // QMODE 1: prepared queries
+    // QMODE 1: prepared queries, frame f's at queries + f * q_stride, nq[f] of them
     const Query *queries;
-    uint32_t n;
+    uint32_t q_stride;
+    uint32_t nq[kMaxBatch];
+    uint32_t n; // queries per frame (QMODE 1: the largest nq[f])
     uint32_t max_steps;
     uint32_t id_bits; // pending ids: query id in the low id_bits, frame above (32: one frame)
     uint8_t prec[3];
@@ -403,10 +406,10 @@ __device__ __forceinline__ bool load_query(const RingArgs &a, uint32_t f, uint32
         make_box(v, a.prec, lo, hi);
         return true;
     } else {
-        if (slot >= a.n)
+        if (slot >= a.nq[f])
             return false;
         q = slot;
-        const Query qq = a.queries[slot];
+        const Query qq = a.queries[(size_t)f * a.q_stride + slot];
         cx = qq.cx;
         cy = qq.cy;
         lo = qq.lo;
@@ -954,7 +957,8 @@ struct PaintArgs {
     uint32_t row_begin, row_end;
     RowPattern rp;
     uint32_t tile_w, tile_h, gx; // uniform tiles
-    const void *groups;          // or list
+    const void *groups_list[kMaxBatch]; // or one list per frame ...
+    uint32_t n_list[kMaxBatch];         // ... of this many groups
     uint32_t n;
     uint32_t raw_stride; // bytes between the frames' raw maps
 };
@@ -1009,20 +1013,22 @@ __global__ __launch_bounds__(256) void paint_1x1_vec4_kernel(PaintArgs a)
 __global__ __launch_bounds__(256) void paint_list_kernel(PaintArgs a)
 {
     __shared__ uint8_t lut[256];
-    build_lut(lut, a.max_word, a.identity, a.max_out);
+    const uint32_t f = blockIdx.y;
+    build_lut(lut, a.max_word + f, a.identity, a.max_out ? a.max_out + f : nullptr);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t g = blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (g >= a.n)
+    if (g >= a.n_list[f])
         return;
-    const GroupRec r = reinterpret_cast<const GroupRec *>(a.groups)[g];
+    const GroupRec r = reinterpret_cast<const GroupRec *>(a.groups_list[f])[g];
     if (r.y < a.row_begin || r.y >= a.row_end || r.x >= a.w)
         return;
-    const uint8_t v = lut[a.raw[g]];
+    const uint8_t v = lut[a.raw[(size_t)f * a.raw_stride + g]];
     const uint32_t w = min(r.w, a.w - r.x), h = min(r.h, a.h - r.y);
     const size_t cells = (size_t)w * h;
+    uint8_t *out = a.out[f];
     for (size_t i = lane; i < cells; i += 64u) {
         const uint32_t yy = r.y + (uint32_t)(i / w), xx = r.x + (uint32_t)(i % w);
-        a.out[0][(size_t)yy * a.ostride + xx] = v;
+        out[(size_t)yy * a.ostride + xx] = v;
     }
 }
 

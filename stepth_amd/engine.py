@@ -259,13 +259,15 @@ class Engine:
         return out[: n.value].copy()
 
     def depth_from_additional_batch(self, mains, additionals, precision, *, max_steps: int = 255,
+                                    tile: Tuple[int, int] = (1, 1),
                                     mode: int = L.MODE_RING_FIRST_HIT, d_max: int = 0, win: int = 0,
                                     rows: Optional[Tuple[int, int]] = None,
                                     row_pattern: Optional[Tuple[int, int, int]] = None,
                                     raw_only: bool = False, gaussian_tail: bool = False,
                                     outs=None, max_out=None, asynchronous: bool = False):
         """stepth_depth_from_additional_batch: many frames of equal shape in one set of launches,
-        ring mode with one group per pixel, or the windowed-SAD mode (`mode`, `d_max`, `win`).  Frames are CUDA uint8 tensors, or numpy arrays (host
+        ring mode with uniform tiles (`tile`, default one group per pixel), or the windowed-SAD
+        mode (`mode`, `d_max`, `win`).  Frames are CUDA uint8 tensors, or numpy arrays (host
         memory: uploaded, computed and downloaded in overlapping chunks; page-locked arrays
         from host_array() copy fastest).  Returns (outs, max): `outs` a list of [H,W] tensors
         / arrays; max a list of ints, or None with asynchronous=True (then `max_out` must be a
@@ -294,7 +296,7 @@ class Engine:
         p.mode = mode
         p.precision = _u8x3(precision)
         p.max_steps = max_steps
-        p.tile_w = p.tile_h = 1
+        p.tile_w, p.tile_h = tile
         p.d_max, p.win = d_max, win
         if rows is not None:
             p.row_begin, p.row_end = rows
@@ -312,6 +314,80 @@ class Engine:
                                                           C.cast(mx, C.c_void_p))
         self._check(st)
         return outs, [int(v) for v in mx]
+
+    def adaptive_groups_batch(self, mains, precision, min_splits: int = 16, max_splits: int = 0,
+                              buffers=None):
+        """stepth_adaptive_groups_batch: adaptive groups of CUDA frames of one shape, one set of
+        launches.  -> (buffers, counts): `buffers` a CUDA uint8 tensor [F, H*W, 20] (pass it
+        back in to reuse it), counts a list of F ints; frame f's groups = buffers[f, :counts[f]]."""
+        import torch
+        self._follow(mains)
+        n = len(mains)
+        mi = (L.Image * n)()
+        keep = []
+        for f in range(n):
+            mi[f], k = _describe(mains[f], (3, 4), "main")
+            keep.append(k)
+        cap = mi[0].width * mi[0].height
+        if buffers is None or tuple(buffers.shape) != (n, cap, 20):
+            buffers = torch.empty((n, cap, 20), dtype=torch.uint8, device=mains[0].device)
+        ptrs = (C.c_void_p * n)(*[buffers[f].data_ptr() for f in range(n)])
+        counts = (C.c_size_t * n)()
+        self._check(self._lib.stepth_adaptive_groups_batch(self._h, n, mi, _u8x3(precision), min_splits,
+                                                           max_splits, ptrs, cap, counts))
+        return buffers, [int(c) for c in counts]
+
+    def depth_from_groups_batch(self, mains, additionals, precision, groups, counts, *,
+                                max_steps: int = 255, rows: Optional[Tuple[int, int]] = None,
+                                raw_only: bool = False, outs=None, max_out=None,
+                                asynchronous: bool = False):
+        """stepth_depth_from_groups_batch: `groups[f]` = CUDA uint8 tensor holding at least
+        counts[f] stepth_group records (20 bytes each) of frame f.  Returns (outs, max)."""
+        import torch
+        self._follow(mains)
+        n = len(mains)
+        if outs is None:
+            outs = [torch.zeros(m.shape[:2], dtype=torch.uint8, device=m.device) for m in mains]
+        mi, ai, di = (L.Image * n)(), (L.Image * n)(), (L.Image * n)()
+        keep = []
+        for f in range(n):
+            mi[f], k1 = _describe(mains[f], (3, 4), "main")
+            ai[f], k2 = _describe(additionals[f], (3,), "additional")
+            di[f], k3 = _describe(outs[f], (1,), "depth")
+            keep += [k1, k2, k3]
+        p = L.Params()
+        p.struct_size = C.sizeof(L.Params)
+        p.mode = L.MODE_RING_FIRST_HIT
+        p.precision = _u8x3(precision)
+        p.max_steps = max_steps
+        p.tile_w = p.tile_h = 1
+        if rows is not None:
+            p.row_begin, p.row_end = rows
+        p.flags = (L.FLAG_ASYNC if asynchronous else 0) | (L.FLAG_RAW_ONLY if raw_only else 0)
+        gp = (C.c_void_p * n)(*[groups[f].data_ptr() for f in range(n)])
+        gn = (C.c_size_t * n)(*[int(c) for c in counts])
+        if asynchronous:
+            mptr = max_out.data_ptr() if max_out is not None else None
+            self._check(self._lib.stepth_depth_from_groups_batch(self._h, n, mi, ai, C.byref(p), gp, gn,
+                                                                 di, mptr))
+            return outs, None
+        mx = (C.c_uint32 * n)()
+        self._check(self._lib.stepth_depth_from_groups_batch(self._h, n, mi, ai, C.byref(p), gp, gn, di,
+                                                             C.cast(mx, C.c_void_p)))
+        return outs, [int(v) for v in mx]
+
+    def adaptive_depth_batch(self, mains, additionals, precision, *, max_steps: int = 255,
+                             min_splits: int = 16, max_splits: int = 0, outs=None,
+                             asynchronous: bool = False):
+        """The path the way the reference runs it (src/depth_image.rs:101-132) for a batch of
+        CUDA frames: adaptive groups (the engine's stand-in for disage) -> ring first hit per
+        group -> normalise -> paint; the groups stay in device memory.  Returns (outs, max)."""
+        self._group_buffers, counts = self.adaptive_groups_batch(
+            mains, precision, min_splits, max_splits, getattr(self, "_group_buffers", None))
+        gb = self._group_buffers
+        return self.depth_from_groups_batch(mains, additionals, precision, [gb[f] for f in range(len(mains))],
+                                            counts, max_steps=max_steps, outs=outs,
+                                            asynchronous=asynchronous)
 
     def host_array(self, shape) -> np.ndarray:
         """uint8 numpy array in page-locked memory (stepth_host_alloc), freed with the array."""

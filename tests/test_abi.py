@@ -36,7 +36,7 @@ def test_header_symbols_all_exported_and_bound(lib):
 
 def test_abi_version_and_status_strings(lib):
     from stepth_amd import _lib
-    assert lib.stepth_abi_version() == _lib.ABI_VERSION == 2
+    assert lib.stepth_abi_version() == _lib.ABI_VERSION == 3
     # the reference's fixed error text, src/depth_image.rs:45-48
     assert lib.stepth_status_string(_lib.ERR_SIZE_MISMATCH) == b"Sizes don't match"
     assert lib.stepth_status_string(0) == b"ok"

@@ -92,3 +92,72 @@ def test_reference_flow_with_adaptive_groups(engine, oracle, asset):
     # and it still resembles the reference's shipped result (tolerance, like the 1x1 pin)
     r = np.corrcoef(ref["depth"].astype(float).ravel(), asset["depth"].astype(float).ravel())[0, 1]
     assert r > 0.9, r
+
+
+@pytest.mark.gpu
+def test_batched_group_flow_matches_oracle(engine, oracle):
+    """the reference's real flow for several frames in one set of launches
+    (stepth_adaptive_groups_batch -> stepth_depth_from_groups_batch): groups as sets, depth
+    maps bit for bit, strips, raw-only; frames with different numbers of groups"""
+    import torch
+    from stepth_amd import synth
+    pairs = [synth.stereo_pair(203, 117, 48, seed=40 + i)[:2] for i in range(5)]
+    pairs.append((np.full((117, 203, 3), 80, np.uint8), pairs[0][1]))  # a flat frame: 2^16 groups at most
+    mains = [torch.from_numpy(np.ascontiguousarray(l)).cuda() for l, _ in pairs]
+    adds = [torch.from_numpy(np.ascontiguousarray(r)).cuda() for _, r in pairs]
+    prec = [36] * 3
+    bufs, counts = engine.adaptive_groups_batch(mains, prec, 12, 0)
+    want_groups = [oracle.adaptive_groups(l, prec, 12, 0) for l, _ in pairs]
+    for f in range(len(pairs)):
+        got = bufs[f, :counts[f]].cpu().numpy().view(oracle.GROUP_DTYPE).ravel()
+        got = got[np.lexsort((got["x"], got["y"]))]
+        w = want_groups[f][np.lexsort((want_groups[f]["x"], want_groups[f]["y"]))]
+        assert counts[f] == len(w) and (got == w).all(), f
+    groups = [bufs[f] for f in range(len(pairs))]
+    outs, mx = engine.depth_from_groups_batch(mains, adds, prec, groups, counts, max_steps=64)
+    for f, (l, r) in enumerate(pairs):
+        ref = oracle.depth_from_additional(l, r, prec, 64, groups=want_groups[f])
+        assert mx[f] == ref["max"] and np.array_equal(outs[f].cpu().numpy(), ref["depth"]), f
+    # a row strip, raw distances: groups whose top row lies in the strip are painted, the rest is 0
+    outs, mx = engine.depth_from_groups_batch(mains, adds, prec, groups, counts, max_steps=64, rows=(30, 90),
+                                              raw_only=True)
+    for f, (l, r) in enumerate(pairs):
+        g = want_groups[f]
+        sel = g[(g["y"] >= 30) & (g["y"] < 90)]
+        m = oracle.match_groups(sel, r, 64, prec)
+        want = oracle.paint(sel, m["raw"], 203, 117)
+        assert np.array_equal(outs[f].cpu().numpy()[30:90], want[30:90]), f
+    # the fused helper
+    outs2, mx2 = engine.adaptive_depth_batch(mains[:3], adds[:3], prec, max_steps=64, min_splits=12)
+    for f in range(3):
+        ref = oracle.depth_from_additional(pairs[f][0], pairs[f][1], prec, 64, groups=want_groups[f])
+        assert np.array_equal(outs2[f].cpu().numpy(), ref["depth"]), f
+
+
+@pytest.mark.gpu
+def test_batched_uniform_tiles_match_oracle(engine, oracle):
+    """stepth_depth_from_additional_batch with tiles larger than one pixel: all frames in one
+    set of launches == the oracle frame by frame; strips; an interleaved row pattern"""
+    import torch
+    from stepth_amd import synth
+    pairs = [synth.stereo_pair(203, 117, 48, seed=70 + i)[:2] for i in range(4)]
+    mains = [torch.from_numpy(np.ascontiguousarray(l)).cuda() for l, _ in pairs]
+    adds = [torch.from_numpy(np.ascontiguousarray(r)).cuda() for _, r in pairs]
+    prec = [36] * 3
+    for tile in ((5, 5), (2, 3), (16, 16), (64, 64)):
+        outs, mx = engine.depth_from_additional_batch(mains, adds, prec, max_steps=64, tile=tile)
+        for f, (l, r) in enumerate(pairs):
+            ref = oracle.depth_from_additional(l, r, prec, 64, tile)
+            assert mx[f] == ref["max"] and np.array_equal(outs[f].cpu().numpy(), ref["depth"]), (tile, f)
+    # a tile larger than the image is the whole image (one group; raw-only: its distance may be 0)
+    outs, mx = engine.depth_from_additional_batch(mains, adds, prec, max_steps=64, tile=(300, 4000), raw_only=True)
+    for f, (l, r) in enumerate(pairs):
+        ref = oracle.depth_from_additional(l, r, prec, 64, (203, 117))
+        assert np.array_equal(outs[f].cpu().numpy(), ref["raw"]), f
+    outs = [torch.full((117, 203), 7, dtype=torch.uint8, device="cuda") for _ in pairs]
+    engine.depth_from_additional_batch(mains, adds, prec, max_steps=64, tile=(5, 5), rows=(20, 60),
+                                       raw_only=True, outs=outs)
+    for f, (l, r) in enumerate(pairs):
+        raw = oracle.depth_from_additional(l, r, prec, 64, (5, 5))["raw"]
+        got = outs[f].cpu().numpy()
+        assert np.array_equal(got[20:60], raw[20:60]) and (got[:20] == 7).all() and (got[60:] == 7).all(), f
