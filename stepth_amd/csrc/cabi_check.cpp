@@ -40,6 +40,40 @@ int main() {
     size_t ng = 0;
     CK(stepth_adaptive_groups(e, &mi[0], p.precision, 16, 0, dg, (size_t)W * H, STEPTH_MEM_DEVICE, &ng));
     CK(stepth_depth_from_additional(e, &mi[0], &ai[0], &p, dg, ng, STEPTH_MEM_DEVICE, &oi, &m1));
+    const std::vector<uint8_t> list_depth = one; // frame 0 through the single-frame list mode
+    // the same flow batched: three device frames, groups never leave the device
+    {
+        const uint32_t B = 3;
+        uint8_t *dm[B], *da[B], *dd[B];
+        stepth_group *gl[B];
+        stepth_image bm[B], ba[B], bd[B];
+        for (uint32_t f = 0; f < B; ++f) {
+            if (hipMalloc(&dm[f], (size_t)W * H * 3) != hipSuccess || hipMalloc(&da[f], (size_t)W * H * 3) != hipSuccess ||
+                hipMalloc(&dd[f], (size_t)W * H) != hipSuccess || hipMalloc(&gl[f], (size_t)W * H * sizeof(stepth_group)) != hipSuccess) {
+                printf("hipMalloc\n");
+                return 1;
+            }
+            (void)hipMemcpy(dm[f], mains[f].data(), (size_t)W * H * 3, hipMemcpyHostToDevice);
+            (void)hipMemcpy(da[f], adds[f].data(), (size_t)W * H * 3, hipMemcpyHostToDevice);
+            bm[f] = stepth_image{dm[f], W, H, 3, STEPTH_MEM_DEVICE, (size_t)W * 3};
+            ba[f] = stepth_image{da[f], W, H, 3, STEPTH_MEM_DEVICE, (size_t)W * 3};
+            bd[f] = stepth_image{dd[f], W, H, 1, STEPTH_MEM_DEVICE, (size_t)W};
+        }
+        size_t counts[B];
+        uint32_t bmx[B];
+        CK(stepth_adaptive_groups_batch(e, B, bm, p.precision, 16, 0, gl, (size_t)W * H, counts));
+        CK(stepth_depth_from_groups_batch(e, B, bm, ba, &p, gl, counts, bd, bmx));
+        std::vector<uint8_t> back((size_t)W * H);
+        (void)hipMemcpy(back.data(), dd[0], back.size(), hipMemcpyDeviceToHost);
+        if (counts[0] != ng || bmx[0] != m1 || back != list_depth) { printf("batched group flow != single\n"); return 1; }
+        // uniform 4x4 tiles, batched == single
+        stepth_params tp = p; tp.tile_w = tp.tile_h = 4;
+        CK(stepth_depth_from_additional_batch(e, B, bm, ba, &tp, bd, bmx));
+        (void)hipMemcpy(back.data(), dd[1], back.size(), hipMemcpyDeviceToHost);
+        CK(stepth_depth_from_additional(e, &mi[1], &ai[1], &tp, nullptr, 0, STEPTH_MEM_HOST, &oi, &m1));
+        if (bmx[1] != m1 || back != one) { printf("batched tiles != single\n"); return 1; }
+        for (uint32_t f = 0; f < B; ++f) { (void)hipFree(dm[f]); (void)hipFree(da[f]); (void)hipFree(dd[f]); (void)hipFree(gl[f]); }
+    }
     std::vector<stepth_group> hg((size_t)W * H);
     CK(stepth_adaptive_groups(e, &mi[0], p.precision, 3, 9, hg.data(), hg.size(), STEPTH_MEM_HOST, &ng));
     // consumers
