@@ -298,8 +298,8 @@ int pack_additional_tiles(stepth_engine *e, uint32_t n_frames, const uint8_t *co
     pa.n_zero = (uint32_t)(kWordsBytes / 4);
     pa.t_stride = (uint32_t)(nblk * 64);
     pa.bb_stride = (uint32_t)bb_frame;
-    hipLaunchKernelGGL(tile_pack_kernel, dim3((bw * pa.nby + 3u) / 4u, n_frames), dim3(256), 0,
-                       e->stream, pa);
+    hipLaunchKernelGGL(tile_pack_kernel, dim3((bw + kPackBlocks - 1u) / kPackBlocks, pa.nby, n_frames),
+                       dim3(256), 0, e->stream, pa);
     TileSuperArgs sa{};
     sa.BBp = pa.BBp;
     sa.bw = bw;

@@ -413,64 +413,117 @@ struct TilePackArgs {
     uint32_t t_stride, bb_stride;
 };
 
-__global__ __launch_bounds__(256) void tile_pack_kernel(TilePackArgs a)
+// One workgroup packs 32 blocks of one block row (256 x 8 pixels): the pixel bytes go through
+// LDS (dword loads when the rows are 4-byte aligned), then thread (block, row) builds the 8
+// cells of its row -- T, row bounds, and by a 3-step exchange the block bounds -- and, after a
+// barrier, thread (block, column) builds its column from the cells left in LDS -- TT, column
+// bounds.  No per-cell shuffles: ~30 instructions per block instead of ~150.
+constexpr uint32_t kPackBlocks = 32;                  // blocks per workgroup
+constexpr uint32_t kPackRowBytes = kPackBlocks * 24u; // 768 pixel bytes per row of the strip
+
+__device__ __forceinline__ void fold_bounds(uint32_t cell, uint32_t (&mn)[3], uint32_t (&mx)[3])
 {
-    const uint32_t lane = threadIdx.x & 63u, f = blockIdx.y;
-    if (blockIdx.x == 0 && f == 0)
-        for (uint32_t i = threadIdx.x; i < a.n_zero; i += blockDim.x)
-            a.zero[i] = 0u;
-    const uint32_t idx = blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (idx >= a.bw * a.nby)
-        return;
-    const uint32_t bx = idx % a.bw, by = a.by0 + idx / a.bw;
-    const uint32_t blk = by * a.bw + bx;
-    const uint32_t x = bx * kBlk + (lane & 7u), y = by * kBlk + (lane >> 3);
-    uint32_t cell = kNoCell;
-    uint32_t mn[3] = {255u, 255u, 255u}, mx[3] = {0u, 0u, 0u};
-    if (x < a.wa && y < a.ha) {
-        const uint8_t *p = a.src[f] + (size_t)y * a.stride + (size_t)x * 3;
-        mn[0] = mx[0] = p[0];
-        mn[1] = mx[1] = p[1];
-        mn[2] = mx[2] = p[2];
-        cell = pack_cell(p[0], p[1], p[2]);
-    }
-    const size_t base = (size_t)f * a.t_stride + (size_t)blk * 64u;
-    a.T[base + lane] = cell;
-    a.TT[base + ((lane & 7u) << 3) + (lane >> 3)] = cell;
-    // line bounds: rows = the 8 lanes with the same lane >> 3, columns = same lane & 7
-    {
-        uint32_t rn[3], rx[3], cn[3], cm[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            rn[c] = cn[c] = mn[c];
-            rx[c] = cm[c] = mx[c];
-#pragma unroll
-            for (int o = 1; o < 8; o <<= 1) {
-                rn[c] = min(rn[c], (uint32_t)__shfl_xor((int)rn[c], o, 64));
-                rx[c] = max(rx[c], (uint32_t)__shfl_xor((int)rx[c], o, 64));
-                cn[c] = min(cn[c], (uint32_t)__shfl_xor((int)cn[c], o * 8, 64));
-                cm[c] = max(cm[c], (uint32_t)__shfl_xor((int)cm[c], o * 8, 64));
-            }
-        }
-        uint2 *lb = a.LB + ((size_t)f * a.t_stride + (size_t)blk * 64u) / 4u; // 16 per block
-        // a line with no cell inside the image gets the empty bounds {0,0}: never matches
-        if ((lane & 7u) == 0)
-            lb[lane >> 3] = rx[0] < rn[0] ? make_uint2(0u, 0u)
-                                          : make_uint2(pack_cell(rx[0], rx[1], rx[2]),
-                                                       pack_cell(rn[0], rn[1], rn[2]));
-        if (lane < 8u)
-            lb[8u + lane] = cm[0] < cn[0] ? make_uint2(0u, 0u)
-                                          : make_uint2(pack_cell(cm[0], cm[1], cm[2]),
-                                                       pack_cell(cn[0], cn[1], cn[2]));
-    }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        mn[c] = wave_min_u32(mn[c]);
-        mx[c] = wave_max_u32(mx[c]);
+        const uint32_t v = (cell >> (10 * c)) & 0xffu;
+        mn[c] = min(mn[c], v);
+        mx[c] = max(mx[c], v);
     }
-    if (lane == 0)
-        a.BBp[(size_t)f * a.bb_stride + (size_t)(by + kPadB) * a.bwp + bx + kPadB] =
-            make_uint2(pack_cell(mx[0], mx[1], mx[2]), pack_cell(mn[0], mn[1], mn[2]));
+}
+
+__global__ __launch_bounds__(256) void tile_pack_kernel(TilePackArgs a)
+{
+    __shared__ uint32_t s_px[8][kPackRowBytes / 4 + 1]; // RGB bytes of the strip, row by row
+    __shared__ uint32_t s_cell[8][kPackBlocks * 8 + 1]; // its cells
+    const uint32_t t = threadIdx.x, f = blockIdx.z;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && f == 0)
+        for (uint32_t i = t; i < a.n_zero; i += 256u)
+            a.zero[i] = 0u;
+    const uint32_t bx0 = blockIdx.x * kPackBlocks, by = a.by0 + blockIdx.y;
+    const uint32_t x0 = bx0 * 8u, y0 = by * 8u;
+    const uint32_t n_px = min(256u, a.wa - x0), n_bytes = n_px * 3u; // pixels / bytes per row here
+    const uint8_t *src = a.src[f] + (size_t)y0 * a.stride + (size_t)x0 * 3u;
+    // ---- pixel bytes -> LDS ----
+    if (((reinterpret_cast<uintptr_t>(src) | a.stride) & 3u) == 0) {
+        for (uint32_t i = t; i < 8u * (kPackRowBytes / 4u); i += 256u) {
+            const uint32_t r = i / (kPackRowBytes / 4u), d = i - r * (kPackRowBytes / 4u);
+            if (y0 + r < a.ha && d * 4u < n_bytes) {
+                const uint8_t *q = src + (size_t)r * a.stride + d * 4u;
+                uint32_t v;
+                if (d * 4u + 4u <= n_bytes) { // whole dword inside the row
+                    v = *reinterpret_cast<const uint32_t *>(q);
+                } else { // the row's last bytes: never read past the image
+                    v = q[0];
+                    if (d * 4u + 1u < n_bytes)
+                        v |= (uint32_t)q[1] << 8;
+                    if (d * 4u + 2u < n_bytes)
+                        v |= (uint32_t)q[2] << 16;
+                }
+                s_px[r][d] = v;
+            }
+        }
+    } else {
+        uint8_t *pb = reinterpret_cast<uint8_t *>(&s_px[0][0]);
+        for (uint32_t i = t; i < 8u * kPackRowBytes; i += 256u) {
+            const uint32_t r = i / kPackRowBytes, b = i - r * kPackRowBytes;
+            if (y0 + r < a.ha && b < n_bytes)
+                pb[r * sizeof(s_px[0]) + b] = src[(size_t)r * a.stride + b];
+        }
+    }
+    __syncthreads();
+    // ---- thread = (block, row): cells of the row, T, row bounds, block bounds ----
+    const uint32_t b = t >> 3, l = t & 7u, bx = bx0 + b;
+    const bool in_blocks = bx < a.bw;
+    const size_t base = (size_t)f * a.t_stride + ((size_t)by * a.bw + bx) * 64u;
+    uint2 *lb = a.LB + base / 4u; // 16 line bounds per block
+    {
+        uint32_t cell[8], mn[3] = {255u, 255u, 255u}, mx[3] = {0u, 0u, 0u};
+        const uint8_t *row = reinterpret_cast<const uint8_t *>(&s_px[l][0]) + b * 24u;
+#pragma unroll
+        for (uint32_t p = 0; p < 8; ++p) {
+            cell[p] = kNoCell;
+            if (x0 + b * 8u + p < a.wa && y0 + l < a.ha) {
+                cell[p] = pack_cell(row[3 * p], row[3 * p + 1], row[3 * p + 2]);
+                fold_bounds(cell[p], mn, mx);
+            }
+            s_cell[l][b * 8u + p] = cell[p];
+        }
+        if (in_blocks) {
+            uint4 *dst = reinterpret_cast<uint4 *>(a.T + base + l * 8u);
+            dst[0] = make_uint4(cell[0], cell[1], cell[2], cell[3]);
+            dst[1] = make_uint4(cell[4], cell[5], cell[6], cell[7]);
+            // a line with no cell inside the image gets the empty bounds {0,0}: never matches
+            lb[l] = mx[0] < mn[0] ? make_uint2(0u, 0u)
+                                  : make_uint2(pack_cell(mx[0], mx[1], mx[2]), pack_cell(mn[0], mn[1], mn[2]));
+        }
+        // the block's bounds: fold the 8 rows (8 consecutive lanes)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int o = 1; o < 8; o <<= 1) {
+                mn[c] = min(mn[c], (uint32_t)__shfl_xor((int)mn[c], o, 64));
+                mx[c] = max(mx[c], (uint32_t)__shfl_xor((int)mx[c], o, 64));
+            }
+        if (in_blocks && l == 0)
+            a.BBp[(size_t)f * a.bb_stride + (size_t)(by + kPadB) * a.bwp + bx + kPadB] =
+                make_uint2(pack_cell(mx[0], mx[1], mx[2]), pack_cell(mn[0], mn[1], mn[2]));
+    }
+    __syncthreads();
+    // ---- thread = (block, column): TT and the column bounds, from the cells in LDS ----
+    if (in_blocks) {
+        uint32_t cell[8], mn[3] = {255u, 255u, 255u}, mx[3] = {0u, 0u, 0u};
+#pragma unroll
+        for (uint32_t p = 0; p < 8; ++p) {
+            cell[p] = s_cell[p][b * 8u + l];
+            if (cell[p] != kNoCell)
+                fold_bounds(cell[p], mn, mx);
+        }
+        uint4 *dst = reinterpret_cast<uint4 *>(a.TT + base + l * 8u);
+        dst[0] = make_uint4(cell[0], cell[1], cell[2], cell[3]);
+        dst[1] = make_uint4(cell[4], cell[5], cell[6], cell[7]);
+        lb[8u + l] = mx[0] < mn[0] ? make_uint2(0u, 0u)
+                                   : make_uint2(pack_cell(mx[0], mx[1], mx[2]), pack_cell(mn[0], mn[1], mn[2]));
+    }
 }
 
 // superblock bounds from the padded block bounds: one wave folds 8x8 blocks

@@ -250,6 +250,22 @@ class EngineStripWorker(StripWorker):
         self.last_base = base  # [F, H, W]; lets the caller gather rows of all frames at once
         return [f[rows[0]:rows[1]] for f in fulls], mx
 
+    def depth_batch(self, frames):
+        """the whole path for every frame in one batched call (one rank: nothing to exchange
+        between PASS 1 and PASS 2) -> (depth u8 [F, H, W], max int32 [F])"""
+        mains = [f[0] for f in frames]
+        adds = [f[1] for f in frames]
+        h, w = mains[0].shape[0], mains[0].shape[1]
+        dev = mains[0].device
+        base = torch.empty((len(frames), h, w), dtype=torch.uint8, device=dev)
+        mx = torch.zeros(len(frames), dtype=torch.int32, device=dev)
+        self.engine.depth_from_additional_batch(mains, adds, self.precision,
+                                                max_steps=self.kw["max_steps"], mode=self.kw["mode"],
+                                                d_max=self.kw["d_max"], win=self.kw["win"],
+                                                outs=[base[i] for i in range(len(frames))],
+                                                max_out=mx, asynchronous=True)
+        return base, mx
+
     def normalise_batch(self, rows_list, max_all, first_row=0, pattern=None):
         if rows_list and rows_list[0].shape[0]:
             self.engine.normalise_rows_batch(rows_list, max_all, asynchronous=True,
@@ -292,7 +308,9 @@ def sharded_depth(worker: StripWorker, frames: Sequence, height: int, width: int
     Returns (depth u8 [F, H, W], max int32 [F]).  Collectives per call (not per frame): one
     all_reduce(MAX) of F words and one exchange of the u8 rows -- `dst=None`: all_gather, every
     rank gets the depth maps; `dst=r`: gather to rank r only (the other ranks return None;
-    each sends its own F*rows*W bytes over its own xGMI link to r, nothing else moves).
+    each sends its own F*rows*W bytes over its own xGMI link to r, nothing else moves);
+    `dst="frames"`: frame f gathers to rank f % world, every rank returns its own frames
+    [n_owned, H, W] (all ranks are sinks, no link carries more than 1/world of the maps).
     `sync` is called before each collective when the worker computes on a side stream.
     `interleave` = B > 0 deals the rows in blocks of B (even, a multiple of tile_h): rank r owns
     blocks r, r+world, ... of every frame -- the work per row is data dependent and very
@@ -323,6 +341,8 @@ def sharded_depth(worker: StripWorker, frames: Sequence, height: int, width: int
 
     batched = getattr(worker, "can_batch", lambda: False)() and n > 0 and \
         hasattr(frames[0][0], "is_cuda") and frames[0][0].is_cuda
+    if world == 1 and batched and hasattr(worker, "depth_batch"):
+        return worker.depth_batch(frames)  # one rank: PASS 1 -> max -> PASS 2 inside one call
     strips, maxes = [], []
     max_buf = None
     prev_us = 0
@@ -344,7 +364,7 @@ def sharded_depth(worker: StripWorker, frames: Sequence, height: int, width: int
             raw, mx = worker.match_strip(f, (r0, r1), **kw)
         strips.append(raw)
         maxes.append(mx)
-    use_pipeline = pipeline is not None and world > 1 and dst is not None and pattern is None
+    use_pipeline = pipeline is not None and world > 1 and isinstance(dst, int) and pattern is None
     if use_pipeline:
         pipeline.finish_previous()  # its transfers ran behind the kernels enqueued above
     if use_balancer:
@@ -411,6 +431,35 @@ def sharded_depth(worker: StripWorker, frames: Sequence, height: int, width: int
                 send[i, : r1 - r0] = raw
     if sync:
         sync()
+    if dst == "frames":
+        # every rank is a sink: frame f's depth map gathers to rank f % world (one gather per
+        # destination, all ranks' links busy at once instead of rank 0's alone).  Returns this
+        # rank's frames rank, rank + world, ... as [n_owned, H, W].
+        own = None
+        for d in range(world):
+            idx = list(range(d, n, world))
+            if not idx:
+                continue
+            part = send[idx].contiguous()
+            part_c = part.cpu() if via_host else part
+            recv_d = (torch.empty((world, len(idx), rows_max, width), dtype=torch.uint8,
+                                  device=torch.device("cpu") if via_host else device)
+                      if rank == d else None)
+            dist.gather(part_c, list(recv_d.unbind(0)) if rank == d else None, dst=d, group=group)
+            if rank == d:
+                recv_d = recv_d.to(device)
+                own = torch.empty((len(idx), height, width), dtype=torch.uint8, device=device)
+                if pattern:
+                    for r in range(world):
+                        if len(owned[r]):
+                            own[:, _owned_on(owned, r, device)] = recv_d[r, :, : len(owned[r])]
+                else:
+                    for r, (a, b) in enumerate(bounds):
+                        if b > a:
+                            own[:, a:b] = recv_d[r, :, : b - a]
+        if own is None:
+            own = torch.empty((0, height, width), dtype=torch.uint8, device=device)
+        return own, max_all
     if dst is not None:
         coll_dev = torch.device("cpu") if via_host else device
         # the root receives straight into one [world, n, rows, W] buffer (views as the list)

@@ -66,13 +66,14 @@ def _worker(rank, world, port, tile, q, dst=None, interleave=0):
         from stepth_amd import synth
         from stepth_amd.sharding import sharded_depth
         frames = []
-        for seed in (1, 2):
+        for seed in (1, 2) if dst != "frames" else (1, 2, 3, 4):
             l, r, _ = synth.stereo_pair(97, 61, 16, seed=seed)
             frames.append((l, r))
         wk = OracleStripWorker([36] * 3, 64, tile)
         depth, mx = sharded_depth(wk, frames, 61, 97, tile_h=tile[1], dst=dst,
                                   interleave=interleave)
-        assert (depth is None) == (dst is not None and rank != dst)
+        if dst != "frames":
+            assert (depth is None) == (dst is not None and rank != dst)
         q.put((rank, None if depth is None else depth.numpy(), mx.numpy()))
         dist.barrier()
     finally:
@@ -306,3 +307,90 @@ def test_pipelined_gather_lags_one_call_and_flushes():
             np.testing.assert_array_equal(last[0], refs[2]["depth"])
         else:
             assert last is None
+
+
+@pytest.mark.parametrize("world,interleave", [(3, 0), (2, 4)])
+def test_every_rank_is_a_sink_frame_f_gathers_to_rank_f_mod_n(world, interleave):
+    """dst="frames": no rank receives more than its share of the depth maps"""
+    from oracle import oracle as O
+    from stepth_amd import synth
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, (1, 1), q, "frames", interleave))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    results = {rank: (depth, mx) for rank, depth, mx in [q.get(timeout=180) for _ in range(world)]}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    refs = [O.depth_from_additional(*synth.stereo_pair(97, 61, 16, seed=s)[:2], [36] * 3, 64) for s in (1, 2, 3, 4)]
+    for rank in range(world):
+        depth, mx = results[rank]
+        mine = list(range(rank, 4, world))
+        assert depth.shape[0] == len(mine)
+        for k, f in enumerate(mine):
+            np.testing.assert_array_equal(depth[k], refs[f]["depth"])
+        assert [int(v) for v in mx] == [r["max"] for r in refs]  # every rank knows every max
+
+
+def _moving_slow_rank(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import time
+        from stepth_amd import synth
+        from stepth_amd.sharding import StripBalancer, sharded_depth
+        pairs = [synth.stereo_pair(97, 61, 16, seed=11 + k)[:2] for k in range(3)]
+        step_no = [0]
+
+        class Moving(OracleStripWorker):  # the slow rank is a different one every step
+            def match_strip(self, frame, rows, max_out=None, pattern=None):
+                out = super().match_strip(frame, rows, max_out, pattern)
+                slow = step_no[0] % world
+                time.sleep(0.02 * (4 if rank == slow else 1) * max(rows[1] - rows[0], 1) / 30)
+                return out
+
+        wk = Moving([36] * 3, 64, (1, 1))
+        bal = StripBalancer(61, world, align=1, min_rows=4)
+        history, depths = [], []
+        for step in range(7):  # content changes every step too: three frame sets cycled
+            step_no[0] = step
+            history.append(list(bal.bounds))
+            depth, mx = sharded_depth(wk, [pairs[step % 3]], 61, 97, balancer=bal)
+            depths.append(depth.numpy().copy())
+        q.put((rank, history, depths))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_balancer_with_a_slow_rank_that_moves_every_step():
+    """frames AND the slow rank change from step to step (the balancer chases a moving target):
+    every rank still derives the same cut points, the cuts stay valid partitions of the rows,
+    and every step's depth map is the oracle's"""
+    from oracle import oracle as O
+    from stepth_amd import synth
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_moving_slow_rank, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    refs = [O.depth_from_additional(*synth.stereo_pair(97, 61, 16, seed=11 + k)[:2], [36] * 3, 64) for k in range(3)]
+    hist0 = results[0][1]
+    assert len({tuple(map(tuple, h)) for h in hist0}) > 1  # the cuts did move
+    for rank, history, depths in results:
+        assert history == hist0
+        for step, d in enumerate(depths):
+            np.testing.assert_array_equal(d[0], refs[step % 3]["depth"])
+    for bounds in hist0:
+        assert bounds[0][0] == 0 and bounds[-1][1] == 61
+        assert all(bounds[k][1] == bounds[k + 1][0] and bounds[k][1] - bounds[k][0] >= 4 for k in range(world - 1))
