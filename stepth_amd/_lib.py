@@ -118,6 +118,7 @@ SYMBOLS = {
     "stepth_apply_mask": (C.c_int, [C.c_void_p, _P(Image), _P(Image), C.c_uint32]),
     "stepth_stats_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "stepth_get_stats": (C.c_int, [C.c_void_p, _P(Stats)]),
+    "stepth_get_stats_raw": (C.c_int, [C.c_void_p, _P(C.c_uint64), C.c_uint32]),
     "stepth_kernel_time_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "stepth_kernel_time_read": (C.c_int, [C.c_void_p, _P(C.c_double), _P(C.c_uint64)]),
 }

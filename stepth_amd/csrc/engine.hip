@@ -42,6 +42,7 @@ struct DevBuf {
 // normalise_rows, [65] pending count, then from word 128 on the kParts run counters of
 // ring_search_kernel
 constexpr uint32_t kWordHostMax = 64, kWordPending = 65, kWordCounters = 128;
+constexpr size_t kStatsBytes = 256; // 8 documented counters + raw slots of tuning builds
 constexpr size_t kWordsBytes = (kWordCounters + kParts * kPartStride) * 4;
 static_assert(kMaxBatch <= (int)kWordHostMax, "per-frame max words");
 
@@ -669,13 +670,13 @@ int stepth_engine_create(int device_id, stepth_engine **out)
     if (hipSetDevice(device_id) != hipSuccess ||
         hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc((void **)&e->words, kWordsBytes) != hipSuccess ||
-        hipMalloc((void **)&e->stats, 64) != hipSuccess) {
+        hipMalloc((void **)&e->stats, kStatsBytes) != hipSuccess) {
         stepth_engine_destroy(e);
         return STEPTH_ERR_HIP;
     }
     e->stream = e->own_stream;
     (void)hipMemsetAsync(e->words, 0, kWordsBytes, e->stream);
-    (void)hipMemsetAsync(e->stats, 0, 64, e->stream);
+    (void)hipMemsetAsync(e->stats, 0, kStatsBytes, e->stream);
     *out = e;
     return STEPTH_OK;
 }
@@ -1043,7 +1044,7 @@ int stepth_depth_from_additional(stepth_engine *e, const stepth_image *main_im,
         TRY(reserve(e, e->raw, std::max<size_t>(ra.n, 4)));
         ra.raw = static_cast<uint8_t *>(e->raw.p);
         if (e->stats_enabled) {
-            HIP_TRY(e, hipMemsetAsync(e->stats, 0, 64, e->stream));
+            HIP_TRY(e, hipMemsetAsync(e->stats, 0, kStatsBytes, e->stream));
             e->stats_groups = ra.n;
         }
         if (use_tile)
@@ -1289,7 +1290,7 @@ static int ring_queries_batch(stepth_engine *e, uint32_t nf, const stepth_image 
     TRY(reserve(e, e->raw, raw_stride * nf));
     ra.raw = static_cast<uint8_t *>(e->raw.p);
     if (e->stats_enabled) {
-        HIP_TRY(e, hipMemsetAsync(e->stats, 0, 64, e->stream));
+        HIP_TRY(e, hipMemsetAsync(e->stats, 0, kStatsBytes, e->stream));
         e->stats_groups = 0;
         for (uint32_t f = 0; f < nf; ++f)
             e->stats_groups += pr.n[f];
@@ -1495,7 +1496,7 @@ int stepth_depth_from_additional_batch(stepth_engine *e, uint32_t n_frames,
         TRY(reserve(e, e->raw, raw_stride * nf));
         ra.raw = static_cast<uint8_t *>(e->raw.p);
         if (e->stats_enabled) {
-            HIP_TRY(e, hipMemsetAsync(e->stats, 0, 64, e->stream));
+            HIP_TRY(e, hipMemsetAsync(e->stats, 0, kStatsBytes, e->stream));
             e->stats_groups = (uint64_t)ra.n * nf;
         }
         if (use_tile)
@@ -1871,7 +1872,7 @@ int stepth_distance_dot_array_batch(stepth_engine *e, const stepth_image *array,
     ra.found = (uint8_t *)e->aux_found.p;
     ra.max_word = e->words;
     if (e->stats_enabled) {
-        HIP_TRY(e, hipMemsetAsync(e->stats, 0, 64, e->stream));
+        HIP_TRY(e, hipMemsetAsync(e->stats, 0, kStatsBytes, e->stream));
         e->stats_groups = n;
     }
     TRY(launch_ring(e, ra, 1));
@@ -1888,7 +1889,7 @@ int stepth_stats_enable(stepth_engine *e, int enable)
         return STEPTH_ERR_BAD_ARG;
     e->stats_enabled = enable != 0;
     e->stats_groups = 0;
-    HIP_TRY(e, hipMemsetAsync(e->stats, 0, 64, e->stream));
+    HIP_TRY(e, hipMemsetAsync(e->stats, 0, kStatsBytes, e->stream));
     return STEPTH_OK;
 }
 
@@ -1908,6 +1909,15 @@ int stepth_get_stats(stepth_engine *e, stepth_stats *out)
     out->survey_steps = h[3];
     out->superblock_steps = h[4];
     out->blocks_probed = h[5];
+    return STEPTH_OK;
+}
+
+int stepth_get_stats_raw(stepth_engine *e, uint64_t *out, uint32_t n)
+{
+    if (!e || !out || n > kStatsBytes / 8)
+        return STEPTH_ERR_BAD_ARG;
+    HIP_TRY(e, hipMemcpyAsync(out, e->stats, (size_t)n * 8, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
     return STEPTH_OK;
 }
 

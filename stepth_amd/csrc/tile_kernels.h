@@ -121,6 +121,7 @@ template <bool STATS>
 __global__ __launch_bounds__(256) void ring_tile_kernel(TileArgs a)
 {
     [[maybe_unused]] unsigned long long pc_tests = 0, pc_survey = 0, pc_probe = 0;
+    [[maybe_unused]] ProbeCounters pcnt{};
     [[maybe_unused]] const unsigned long long pc_t0 = STEPTH_TICK();
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wv = rfl(threadIdx.x >> 6);
@@ -331,6 +332,7 @@ __global__ __launch_bounds__(256) void ring_tile_kernel(TileArgs a)
                 if (!__builtin_amdgcn_ballot_w64(cur != 0ull))
                     continue;
                 while (cur != 0ull) {
+                    STEPTH_CNT(&pcnt, 0);
                     const int k = __builtin_ctzll(cur);
                     cur &= cur - 1ull;
                     const int bx = bx0 + (k & 7), by = by0 + (k >> 3);
@@ -345,7 +347,7 @@ __global__ __launch_bounds__(256) void ring_tile_kernel(TileArgs a)
                         const uint32_t boff = tf + ((uint32_t)by * a.bw + (uint32_t)bx) * 64u;
                         const uint32_t nl =
                             probe_block(q, x0, y0, pb, a.T + boff, a.TT + boff,
-                                        reinterpret_cast<const uint32_t *>(a.LB) + (boff >> 1));
+                                        reinterpret_cast<const uint32_t *>(a.LB) + (boff >> 1), &pcnt);
                         if constexpr (STATS) {
                             ++n_probed;
                             n_tests += 8u * nl;
@@ -381,7 +383,25 @@ __global__ __launch_bounds__(256) void ring_tile_kernel(TileArgs a)
         if (lane == 0) {
             atomicAdd(&a.stats[0], v0);
             atomicAdd(&a.stats[1], v1);
-#ifdef STEPTH_TILE_PROFILE
+#if defined(STEPTH_TILE_PROFILE) && STEPTH_TILE_PROFILE == 2
+        }
+        for (int i = 0; i < 7; ++i) { // raw slots 8.. : lane counts, 16.. : wave counts
+            unsigned long long lv = pcnt.lane[i], wv2 = pcnt.wave[i];
+            for (int o = 32; o > 0; o >>= 1) {
+                lv += __shfl_xor(lv, o, 64);
+                wv2 += __shfl_xor(wv2, o, 64);
+            }
+            if (lane == 0) {
+                atomicAdd(&a.stats[8 + i], lv);
+                atomicAdd(&a.stats[16 + i], wv2);
+            }
+        }
+        if (lane == 0) {
+            atomicAdd(&a.stats[2], n_near);
+            atomicAdd(&a.stats[3], n_survey);
+            atomicAdd(&a.stats[4], n_super);
+            atomicAdd(&a.stats[5], v5);
+#elif defined(STEPTH_TILE_PROFILE)
             atomicAdd(&a.stats[2], pc_tests);
             atomicAdd(&a.stats[3], pc_survey);
             atomicAdd(&a.stats[4], pc_probe);

@@ -33,6 +33,29 @@ namespace stepth {
 constexpr uint32_t kTileNoKey = 0xFFFFFFFFu;
 #endif
 
+// Tuning builds (-DSTEPTH_TILE_PROFILE=2) count how often each section of the probe runs, per
+// lane and per wave (a wave runs a section whenever one of its lanes does); never in the
+// shipped library.
+#if defined(STEPTH_TILE_PROFILE) && STEPTH_TILE_PROFILE == 2
+struct ProbeCounters {
+    uint32_t lane[8], wave[8]; // 0 pop, 1 probe, 2 side entered, 3 bounds tested, 4 line, 5 hit path, 6 hit
+};
+#if defined(__HIP_DEVICE_COMPILE__)
+#define STEPTH_CNT(PC, I)                                                                      \
+    do {                                                                                       \
+        ++(PC)->lane[I];                                                                       \
+        const unsigned long long m_ = __builtin_amdgcn_ballot_w64(true);                       \
+        if ((uint32_t)__builtin_ctzll(m_) == (threadIdx.x & 63u))                              \
+            ++(PC)->wave[I];                                                                   \
+    } while (0)
+#else
+#define STEPTH_CNT(PC, I) ((void)0)
+#endif
+#else
+struct ProbeCounters {};
+#define STEPTH_CNT(PC, I) ((void)0)
+#endif
+
 struct LaneQ {
     int qx, qy;      // search centre `middle` (depth_image.rs:114-117), additional-image cells
     uint32_t lo, hi; // colour box (cell_pack.h make_box)
@@ -99,8 +122,9 @@ struct LineTest {
 // a line whose bounds meet the box is read.  Returns the lines read.
 template <int SIDE>
 STEPTH_HD uint32_t scan_side(LaneQ &q, int a0, int b0, int mdb, uint32_t pb, const uint32_t *tbl,
-                             const uint32_t *lb)
+                             const uint32_t *lb, [[maybe_unused]] ProbeCounters *pc = nullptr)
 {
+    STEPTH_CNT(pc, 2);
     constexpr bool neg = SIDE & 1;
     constexpr int strict = SIDE < 2 ? 0 : 1; // corners belong to the rows (helpers.rs:28-31)
     const int s_base = neg ? -(a0 + 7) : a0; // ring of the line with index 0 in scan order
@@ -110,6 +134,7 @@ STEPTH_HD uint32_t scan_side(LaneQ &q, int a0, int b0, int mdb, uint32_t pb, con
     if (first > s_base + 7 || (uint32_t)first >= q.limit)
         return 0;
     uint32_t cand = 0; // bit i: line i (scan order) may hold a match
+    STEPTH_CNT(pc, 3);
     {
 #if defined(__HIP_DEVICE_COMPILE__)
         const uint4 *l4 = reinterpret_cast<const uint4 *>(lb);
@@ -123,11 +148,37 @@ STEPTH_HD uint32_t scan_side(LaneQ &q, int a0, int b0, int mdb, uint32_t pb, con
             bn[i] = lb[2 * i + 1];
         }
 #endif
-#pragma unroll
+#if defined(__HIP_DEVICE_COMPILE__)
+        // five VALU instructions per bound: t = max - lo, u = hi - min, r = (t & u) | ~guard,
+        // vcc = (r == ~0), cand = cand + cand + vcc (highest scan index first)
+        uint32_t t, u;
+        const uint32_t ng = ~kGuard;
+#define STEPTH_LT(MX, MN)                                                                      \
+    "v_sub_u32 %1, " MX ", %3\n v_sub_u32 %2, %4, " MN "\n v_and_or_b32 %1, %1, %2, %5\n"        \
+    "v_cmp_eq_u32 vcc, -1, %1\n v_addc_co_u32 %0, vcc, %0, %0, vcc\n"
+        if constexpr (neg)
+            asm(STEPTH_LT("%6", "%7") STEPTH_LT("%8", "%9") STEPTH_LT("%10", "%11") STEPTH_LT("%12", "%13")
+                    STEPTH_LT("%14", "%15") STEPTH_LT("%16", "%17") STEPTH_LT("%18", "%19") STEPTH_LT("%20", "%21")
+                : "+v"(cand), "=&v"(t), "=&v"(u)
+                : "v"(q.lo), "v"(q.hi), "s"(ng), "v"(bx[0]), "v"(bn[0]), "v"(bx[1]), "v"(bn[1]), "v"(bx[2]),
+                  "v"(bn[2]), "v"(bx[3]), "v"(bn[3]), "v"(bx[4]), "v"(bn[4]), "v"(bx[5]), "v"(bn[5]),
+                  "v"(bx[6]), "v"(bn[6]), "v"(bx[7]), "v"(bn[7])
+                : "vcc");
+        else
+            asm(STEPTH_LT("%20", "%21") STEPTH_LT("%18", "%19") STEPTH_LT("%16", "%17") STEPTH_LT("%14", "%15")
+                    STEPTH_LT("%12", "%13") STEPTH_LT("%10", "%11") STEPTH_LT("%8", "%9") STEPTH_LT("%6", "%7")
+                : "+v"(cand), "=&v"(t), "=&v"(u)
+                : "v"(q.lo), "v"(q.hi), "s"(ng), "v"(bx[0]), "v"(bn[0]), "v"(bx[1]), "v"(bn[1]), "v"(bx[2]),
+                  "v"(bn[2]), "v"(bx[3]), "v"(bn[3]), "v"(bx[4]), "v"(bn[4]), "v"(bx[5]), "v"(bn[5]),
+                  "v"(bx[6]), "v"(bn[6]), "v"(bx[7]), "v"(bn[7])
+                : "vcc");
+#undef STEPTH_LT
+#else
         for (int i = 7; i >= 0; --i) { // highest scan index first: it ends in the highest bit
             const int l = neg ? 7 - i : i;
             cand = cand + cand + (box_meets(bx[l], bn[l], q.lo, q.hi) ? 1u : 0u);
         }
+#endif
     }
     cand &= 0xFFu << (first - s_base);
     uint32_t n_lines = 0;
@@ -142,11 +193,14 @@ STEPTH_HD uint32_t scan_side(LaneQ &q, int a0, int b0, int mdb, uint32_t pb, con
         LineTest t;
         t.load(tbl + line * 8, q.lo, q.hi);
         ++n_lines;
+        STEPTH_CNT(pc, 4);
         if (t.any()) {
+            STEPTH_CNT(pc, 5);
             const int r = s - strict; // cells with |b| <= r belong to this side
             const int p0 = imax(0, -r - b0), p1 = imin(7, r - b0);
             const uint32_t hits = t.bits() & (0xFFu >> (7 - p1)) & (0xFFu << p0);
             if (hits) {
+                STEPTH_CNT(pc, 6);
                 const int p = __builtin_ctz(hits);
                 const uint32_t key =
                     ((((uint32_t)s << 2) | (uint32_t)SIDE) << pb) | (uint32_t)(b0 + p + s);
@@ -164,13 +218,15 @@ STEPTH_HD uint32_t scan_side(LaneQ &q, int a0, int b0, int mdb, uint32_t pb, con
 // bounds (8 rows, then 8 columns; uint2 {max,min} each); pb = position bits of the key.
 // Returns the number of lines read (statistics).
 STEPTH_HD uint32_t probe_block(LaneQ &q, int x0, int y0, uint32_t pb, const uint32_t *rows,
-                               const uint32_t *cols, const uint32_t *lb)
+                               const uint32_t *cols, const uint32_t *lb,
+                               [[maybe_unused]] ProbeCounters *pc = nullptr)
 {
+    STEPTH_CNT(pc, 1);
     const int mdx = imax(imax(x0, -(x0 + 7)), 0), mdy = imax(imax(y0, -(y0 + 7)), 0);
-    uint32_t n = scan_side<0>(q, y0, x0, mdx, pb, rows, lb);
-    n += scan_side<1>(q, y0, x0, mdx, pb, rows, lb);
-    n += scan_side<2>(q, x0, y0, mdy, pb, cols, lb + 16);
-    n += scan_side<3>(q, x0, y0, mdy, pb, cols, lb + 16);
+    uint32_t n = scan_side<0>(q, y0, x0, mdx, pb, rows, lb, pc);
+    n += scan_side<1>(q, y0, x0, mdx, pb, rows, lb, pc);
+    n += scan_side<2>(q, x0, y0, mdy, pb, cols, lb + 16, pc);
+    n += scan_side<3>(q, x0, y0, mdy, pb, cols, lb + 16, pc);
     return n;
 }
 
