@@ -94,8 +94,16 @@ class PlaneList:
     def __init__(self, tensors, channels=(1,), name: str = "plane"):
         self.tensors = list(tensors)
         self.images = (L.Image * len(self.tensors))()
+        self._keep = []
         for f, t in enumerate(self.tensors):
-            self.images[f], _keep = _describe(t, channels, name)
+            self.images[f], k = _describe(t, channels, name)
+            self._keep.append(k)
+
+    def __len__(self):
+        return len(self.tensors)
+
+    def __getitem__(self, i):
+        return self.tensors[i]
 
 
 class Engine:
@@ -272,25 +280,26 @@ class Engine:
         from host_array() copy fastest).  Returns (outs, max): `outs` a list of [H,W] tensors
         / arrays; max a list of ints, or None with asynchronous=True (then `max_out` must be a
         CUDA int32 tensor with one element per frame, or None)."""
-        self._follow(mains)
+        self._follow(mains.tensors if isinstance(mains, PlaneList) else mains)
         n = len(mains)
         if n == 0 or len(additionals) != n:
             raise ValueError("mains and additionals must be equally long, non-empty lists")
         if outs is None:
-            if _is_tensor(mains[0]):
-                import torch
-                outs = [torch.zeros(m.shape[:2], dtype=torch.uint8, device=m.device) for m in mains]
+            if isinstance(mains, PlaneList):
+                mains_t = mains.tensors
             else:
-                outs = [np.zeros(m.shape[:2], np.uint8) for m in mains]
-        mi = (L.Image * n)()
-        ai = (L.Image * n)()
-        di = (L.Image * n)()
-        keep = []
-        for f in range(n):
-            mi[f], k1 = _describe(mains[f], (3, 4), "main")
-            ai[f], k2 = _describe(additionals[f], (3,), "additional")
-            di[f], k3 = _describe(outs[f], (1,), "depth")
-            keep += [k1, k2, k3]
+                mains_t = mains
+            if _is_tensor(mains_t[0]):
+                import torch
+                outs = [torch.zeros(m.shape[:2], dtype=torch.uint8, device=m.device) for m in mains_t]
+            else:
+                outs = [np.zeros(m.shape[:2], np.uint8) for m in mains_t]
+        # PlaneList arguments carry their descriptions (built once): a step of 64 frames is 192
+        # images, and describing them anew on every call costs the host more than the GPU takes
+        mi = mains.images if isinstance(mains, PlaneList) else PlaneList(mains, (3, 4), "main").images
+        ai = additionals.images if isinstance(additionals, PlaneList) else \
+            PlaneList(additionals, (3,), "additional").images
+        di = outs.images if isinstance(outs, PlaneList) else PlaneList(outs, (1,), "depth").images
         p = L.Params()
         p.struct_size = C.sizeof(L.Params)
         p.mode = mode
@@ -422,13 +431,9 @@ class Engine:
                              row_pattern: Optional[Tuple[int, int, int]] = None):
         """stepth_normalise_rows_batch: PASS 2 on equally shaped CUDA views in one launch;
         `max_tensor` holds one int32 per view."""
-        self._follow(rows_list)
+        self._follow(rows_list.tensors if isinstance(rows_list, PlaneList) else rows_list)
         n = len(rows_list)
-        ri = (L.Image * n)()
-        keep = []
-        for f in range(n):
-            ri[f], k = _describe(rows_list[f], (1,), "rows")
-            keep.append(k)
+        ri = rows_list.images if isinstance(rows_list, PlaneList) else PlaneList(rows_list, (1,), "rows").images
         rb, rm, rr = row_pattern if row_pattern is not None else (0, 1, 0)
         self._check(self._lib.stepth_normalise_rows_batch(
             self._h, n, ri, first_row, rb, rm, rr, max_tensor.data_ptr(),

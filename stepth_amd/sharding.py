@@ -209,6 +209,7 @@ class EngineStripWorker(StripWorker):
         self.engine = engine
         self.kw = dict(max_steps=max_steps, tile=tile, mode=mode, d_max=d_max, win=win)
         self.precision = list(precision)
+        self._sets = {}  # id(frames) -> described frame set (see _described)
 
     def match_strip(self, frame, rows, max_out=None, pattern=None):
         main, add = frame
@@ -231,14 +232,29 @@ class EngineStripWorker(StripWorker):
     def can_batch(self) -> bool:
         return self.kw["mode"] == 1 or tuple(self.kw["tile"]) == (1, 1)
 
+    def _described(self, frames):
+        """ctypes descriptions of a frame set and of the output planes that go with it, built
+        once per frame set (a step of 64 frames is 192 images; describing them on every call
+        costs the host more than the kernels take).  The output planes are reused from call to
+        call: everything that reads them is enqueued on the same stream before the next call."""
+        from .engine import PlaneList
+        key = id(frames)
+        hit = self._sets.get(key)
+        if hit is None or hit[0] is not frames:
+            mains = PlaneList([f[0] for f in frames], (3, 4), "main")
+            adds = PlaneList([f[1] for f in frames], (3,), "additional")
+            h, w = frames[0][0].shape[0], frames[0][0].shape[1]
+            base = torch.empty((len(frames), h, w), dtype=torch.uint8, device=frames[0][0].device)
+            outs = PlaneList([base[i] for i in range(len(frames))], (1,), "depth")
+            if len(self._sets) > 8:
+                self._sets.clear()
+            hit = self._sets[key] = (frames, mains, adds, base, outs, {})
+        return hit
+
     def match_batch(self, frames, rows, pattern=None):
         """PASS 1 for every frame -> (list of raw views [r1-r0, W], max int32 [F])."""
-        mains = [f[0] for f in frames]
-        adds = [f[1] for f in frames]
-        h, w = mains[0].shape[0], mains[0].shape[1]
-        dev = mains[0].device
-        base = torch.empty((len(frames), h, w), dtype=torch.uint8, device=dev)
-        fulls = [base[i] for i in range(len(frames))]  # all frames in one allocation
+        _f, mains, adds, base, fulls, _views = self._described(frames)
+        dev = base.device
         mx = torch.zeros(len(frames), dtype=torch.int32, device=dev)
         if rows[1] > rows[0]:
             self.engine.depth_from_additional_batch(mains, adds, self.precision,
@@ -248,26 +264,28 @@ class EngineStripWorker(StripWorker):
                                                     row_pattern=pattern, raw_only=True,
                                                     outs=fulls, max_out=mx, asynchronous=True)
         self.last_base = base  # [F, H, W]; lets the caller gather rows of all frames at once
-        return [f[rows[0]:rows[1]] for f in fulls], mx
+        views = _views.get(rows)
+        if views is None:  # the strips as a described list (normalise_batch), per cut
+            from .engine import PlaneList
+            if len(_views) > 16:
+                _views.clear()
+            views = _views[rows] = PlaneList([base[i, rows[0]:rows[1]] for i in range(len(frames))], (1,), "rows") \
+                if rows[1] > rows[0] else [base[i, rows[0]:rows[1]] for i in range(len(frames))]
+        return views, mx
 
     def depth_batch(self, frames):
         """the whole path for every frame in one batched call (one rank: nothing to exchange
         between PASS 1 and PASS 2) -> (depth u8 [F, H, W], max int32 [F])"""
-        mains = [f[0] for f in frames]
-        adds = [f[1] for f in frames]
-        h, w = mains[0].shape[0], mains[0].shape[1]
-        dev = mains[0].device
-        base = torch.empty((len(frames), h, w), dtype=torch.uint8, device=dev)
-        mx = torch.zeros(len(frames), dtype=torch.int32, device=dev)
+        _f, mains, adds, base, outs, _views = self._described(frames)
+        mx = torch.zeros(len(frames), dtype=torch.int32, device=base.device)
         self.engine.depth_from_additional_batch(mains, adds, self.precision,
                                                 max_steps=self.kw["max_steps"], mode=self.kw["mode"],
                                                 d_max=self.kw["d_max"], win=self.kw["win"],
-                                                outs=[base[i] for i in range(len(frames))],
-                                                max_out=mx, asynchronous=True)
+                                                outs=outs, max_out=mx, asynchronous=True)
         return base, mx
 
     def normalise_batch(self, rows_list, max_all, first_row=0, pattern=None):
-        if rows_list and rows_list[0].shape[0]:
+        if len(rows_list) and rows_list[0].shape[0]:
             self.engine.normalise_rows_batch(rows_list, max_all, asynchronous=True,
                                              first_row=first_row, row_pattern=pattern)
 
@@ -305,7 +323,9 @@ def sharded_depth(worker: StripWorker, frames: Sequence, height: int, width: int
                   ) -> Tuple[Optional[torch.Tensor], torch.Tensor]:
     """Depth maps of `frames`, every frame row-strip sharded over the ranks of `group`.
 
-    Returns (depth u8 [F, H, W], max int32 [F]).  Collectives per call (not per frame): one
+    Returns (depth u8 [F, H, W], max int32 [F]).  With one rank and an EngineStripWorker the
+    maps are the worker's own output planes for this frame list: valid until its next call
+    with the same list (copy them to keep them).  Collectives per call (not per frame): one
     all_reduce(MAX) of F words and one exchange of the u8 rows -- `dst=None`: all_gather, every
     rank gets the depth maps; `dst=r`: gather to rank r only (the other ranks return None;
     each sends its own F*rows*W bytes over its own xGMI link to r, nothing else moves);
