@@ -117,8 +117,11 @@ __device__ __forceinline__ uint32_t wave_max_dpp(uint32_t v)
 #define STEPTH_TICK() 0ull
 #endif
 
+// <= 80 SGPRs keep 8 workgroups of 256 threads resident per CU (MI355X_MICROARCH.md,
+// "Residency": 800 / (sgprs + 16)); the kernel wants 106, the spills to vector lanes cost less
+// than the eighth wave per SIMD brings (1.28 -> 1.22 ms; 96: 1.23, 64: 1.24)
 template <bool STATS>
-__global__ __launch_bounds__(256) void ring_tile_kernel(TileArgs a)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void ring_tile_kernel(TileArgs a)
 {
     [[maybe_unused]] unsigned long long pc_tests = 0, pc_survey = 0, pc_probe = 0;
     [[maybe_unused]] ProbeCounters pcnt{};
