@@ -1318,8 +1318,9 @@ static int ring_queries_batch(stepth_engine *e, uint32_t nf, const stepth_image 
         for (uint32_t f = 0; f < nf; ++f) {
             pa.groups_list[f] = d_groups[f];
             pa.n_list[f] = n_groups[f];
-            HIP_TRY(e, hipMemset2DAsync(pa.out[f] + (size_t)row0 * pa.ostride, pa.ostride, 0, W, rows, e->stream));
         }
+        hipLaunchKernelGGL(zero_rows_kernel, dim3((uint32_t)std::min<size_t>(((size_t)rows * W + 255) / 256, 512), nf),
+                           dim3(256), 0, e->stream, pa);
         hipLaunchKernelGGL(paint_list_kernel, dim3((n_max + 3) / 4, nf), dim3(256), 0, e->stream, pa);
     } else {
         pa.tile_w = p.tile_w;

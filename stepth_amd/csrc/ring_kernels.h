@@ -1180,6 +1180,17 @@ __global__ __launch_bounds__(256) void gauss_horizontal4_kernel(Gauss4Args a)
     }
 }
 
+// clears rows [row_begin,row_end) of every frame's depth map (group lists: pixels no group of
+// the strip covers must read 0, like ImageBuffer::from_pixel(.., Luma([0])), depth_image.rs:20)
+__global__ __launch_bounds__(256) void zero_rows_kernel(PaintArgs a)
+{
+    uint8_t *out = a.out[blockIdx.y];
+    const size_t total = (size_t)(a.row_end - a.row_begin) * a.w;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x)
+        out[(size_t)(a.row_begin + (uint32_t)(i / a.w)) * a.ostride + (i % a.w)] = 0;
+}
+
 __global__ void zero_words_kernel(uint32_t *p, int n)
 {
     if ((int)threadIdx.x < n)
