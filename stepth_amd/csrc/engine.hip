@@ -56,6 +56,7 @@ struct stepth_engine {
     DevBuf TT, LB, BBp, SBp; // dense search (tile_kernels.h): column-major cells, line bounds, padded bounds
     uint32_t bbp_layout[3] = {0, 0, 0}; // bw, bh, frames the zero border of BBp was laid out for
     DevBuf stage_main, stage_add, stage_out, stage_groups;
+    DevBuf queries_sorted, query_ids, query_bins; // group lists sorted by search-centre bin
     DevBuf queries, raw, aux32, aux_pos, aux_found, pending, pending_rec, pending_key;
     DevBuf sad_left, sad_right, gauss_tmp, gauss_io;
     DevBuf zone_counts, zone_tables; // depth_split: 256 counts and one ZoneTable per frame
@@ -385,6 +386,59 @@ int launch_tile(stepth_engine *e, const RingArgs &ra, uint32_t n_frames)
     return STEPTH_OK;
 }
 
+// PASS 1 for prepared queries (group lists, tiles > 1x1, distance_dot_array_batch) on the
+// per-lane kernel (tile_kernels.h: ring_list_kernel); `ra` as for launch_ring with qmode 1.
+int launch_list(stepth_engine *e, const RingArgs &ra, uint32_t n_frames)
+{
+    if (ra.n == 0)
+        return STEPTH_OK;
+    ListArgs la{};
+    la.T = (const uint32_t *)e->T.p;
+    la.TT = (const uint32_t *)e->TT.p;
+    la.LB = (const uint2 *)e->LB.p;
+    la.BBp = (const uint2 *)e->BBp.p;
+    la.SBp = (const uint2 *)e->SBp.p;
+    la.wa = ra.wa;
+    la.ha = ra.ha;
+    la.bw = ra.bw;
+    la.bh = ra.bh;
+    la.bwp = tile_bwp(ra.bw);
+    la.sbwp = tile_sbwp(ra.sbw);
+    la.t_stride = ra.bw * ra.bh * 64u;
+    la.bb_stride = la.bwp * tile_bhp(ra.bh);
+    la.sb_stride = la.sbwp * ra.sbh;
+    la.queries = ra.queries;
+    la.ids = ra.query_ids;
+    la.q_stride = ra.q_stride;
+    for (uint32_t f = 0; f < n_frames; ++f)
+        la.nq[f] = ra.nq[f];
+    la.max_steps = std::min(ra.max_steps, std::max(ra.wa, ra.ha));
+    {
+        const uint32_t top = std::max(la.max_steps, 2u) - 1u;
+        uint32_t pb = 1;
+        while ((2u * top) >> pb)
+            ++pb;
+        la.pos_bits = pb;
+    }
+    la.raw = ra.raw;
+    la.raw_stride = (uint32_t)(((size_t)ra.n + 3u) & ~(size_t)3u);
+    la.raw32 = ra.raw32;
+    la.pos = ra.pos;
+    la.found = ra.found;
+    la.max_word = ra.max_word;
+    la.stats = e->stats_enabled ? e->stats : nullptr;
+    const dim3 grid((ra.n + 255u) / 256u, n_frames), block(256);
+    {
+        KernelTimer t(e);
+        if (e->stats_enabled)
+            hipLaunchKernelGGL(ring_list_kernel<true>, grid, block, 0, e->stream, la);
+        else
+            hipLaunchKernelGGL(ring_list_kernel<false>, grid, block, 0, e->stream, la);
+    }
+    HIP_TRY(e, hipGetLastError());
+    return STEPTH_OK;
+}
+
 // Block-spiral table of ring_match_kernel (query independent): enough chunks for the rings a
 // search of `max_steps` steps can reach in an array of wa x ha cells.
 int ensure_spiral(stepth_engine *e, uint32_t max_steps, uint32_t wa, uint32_t ha)
@@ -688,7 +742,7 @@ void stepth_engine_destroy(stepth_engine *e)
     (void)hipSetDevice(e->device);
     (void)hipStreamSynchronize(e->stream);
     for (DevBuf *b : {&e->T, &e->BB, &e->SB, &e->TT, &e->LB, &e->BBp, &e->SBp, &e->spiral, &e->stage_main, &e->stage_add, &e->stage_out,
-                      &e->stage_groups, &e->queries, &e->raw, &e->aux32, &e->aux_pos,
+                      &e->stage_groups, &e->queries, &e->queries_sorted, &e->query_ids, &e->query_bins, &e->raw, &e->aux32, &e->aux_pos,
                       &e->aux_found, &e->pending, &e->pending_rec, &e->pending_key, &e->sad_left, &e->sad_right, &e->gauss_tmp, &e->gauss_io,
                       &e->zone_counts, &e->zone_tables, &e->pipe_main[0], &e->pipe_main[1],
                       &e->pipe_add[0], &e->pipe_add[1], &e->pipe_out[0], &e->pipe_out[1], &e->pipe_max, &e->group_out,
@@ -760,6 +814,12 @@ int stepth_engine_sync(stepth_engine *e)
 }
 
 const char *stepth_last_error(const stepth_engine *e) { return e ? e->err.c_str() : "null engine"; }
+
+static int ring_queries_batch(stepth_engine *e, uint32_t nf, const stepth_image *mains,
+                              const stepth_image *adds, const stepth_params &p, uint32_t row0,
+                              uint32_t row1, RowPattern rp, const void *const *d_groups,
+                              const uint32_t *n_groups, const stepth_image *depths,
+                              uint32_t *max_out, bool &any_zero);
 
 int stepth_depth_from_additional(stepth_engine *e, const stepth_image *main_im,
                                  const stepth_image *add_im, const stepth_params *pp,
@@ -897,27 +957,56 @@ int stepth_depth_from_additional(stepth_engine *e, const stepth_image *main_im,
             hipLaunchKernelGGL(paint_tiles_kernel, dim3(blocks), dim3(256), 0, e->stream, pa);
             HIP_TRY(e, hipGetLastError());
         }
-    } else if (p.mode == STEPTH_MODE_RING_FIRST_HIT) {
-        uint32_t bw = 0, bh = 0;
-        bool use_tile = false; // one group per pixel: the dense search (tile_kernels.h)
-        {
-            // rows of the additional image the strip's searches can reach: the centres of
-            // uniform tiles lie in rows [row0/2, (row1+tile_h)/2], every search stays within
-            // max_steps-1 rings of its centre (group lists: unknown centres, pack everything)
-            uint32_t lo = 0, hi = 0xFFFFFFFFu;
-            if (!groups && p.tile_h && p.max_steps < 0x40000000u) { // (a pattern keeps row0..row1)
-                const uint32_t reach = p.max_steps ? p.max_steps - 1u : 0u;
-                const uint32_t c_lo = row0 / 2u, c_hi = (row1 + p.tile_h) / 2u;
-                lo = c_lo > reach ? c_lo - reach : 0u;
-                hi = c_hi + reach + 1u;
+    } else if (p.mode == STEPTH_MODE_RING_FIRST_HIT && (groups || p.tile_w != 1 || p.tile_h != 1)) {
+        // prepared queries (an explicit group list, or uniform tiles larger than one pixel): the
+        // same code as a batch of one frame, on the device copies of the images
+        if (!groups && (p.tile_w == 0 || p.tile_h == 0))
+            return fail(e, STEPTH_ERR_BAD_ARG, "tile size 0");
+        if (!groups && (row0 % p.tile_h != 0 || (row1 % p.tile_h != 0 && row1 != H)))
+            return fail(e, STEPTH_ERR_BAD_ARG, "row strip [%u,%u) not aligned to tile_h %u", row0, row1,
+                        p.tile_h);
+        const void *d_groups = nullptr;
+        uint32_t ng = 0;
+        if (groups) {
+            if (n_groups == 0 || n_groups > 0xFFFFFF00ull)
+                return fail(e, STEPTH_ERR_BAD_ARG, "group list of %zu entries", n_groups);
+            ng = (uint32_t)n_groups;
+            if (groups_memory == STEPTH_MEM_DEVICE) {
+                d_groups = groups;
+            } else {
+                TRY(reserve(e, e->stage_groups, n_groups * sizeof(stepth_group)));
+                HIP_TRY(e, hipMemcpyAsync(e->stage_groups.p, groups, n_groups * sizeof(stepth_group),
+                                          hipMemcpyHostToDevice, e->stream));
+                d_groups = e->stage_groups.p;
             }
-            use_tile = !groups && p.tile_w == 1 && p.tile_h == 1 &&
-                       tile_search_fits(p.max_steps, add_im->width, add_im->height);
-            if (use_tile)
-                TRY(pack_additional_tiles(e, 1, &d_add, as, add_im->width, add_im->height, bw, bh, lo, hi));
-            else
-                TRY(pack_additional(e, 1, &d_add, as, add_im->width, add_im->height, bw, bh, lo, hi));
         }
+        const stepth_image dm{d_main, W, H, main_im->channels, STEPTH_MEM_DEVICE, ms};
+        const stepth_image da{d_add, add_im->width, add_im->height, 3, STEPTH_MEM_DEVICE, as};
+        const stepth_image dd{d_out, W, H, 1, STEPTH_MEM_DEVICE, os};
+        stepth_params ap = p;
+        ap.flags |= STEPTH_FLAG_ASYNC; // this function reads the max back itself
+        bool any_zero = false;
+        TRY(ring_queries_batch(e, 1, &dm, &da, ap, row0, row1, rp, groups ? &d_groups : nullptr, &ng, &dd,
+                               async ? max_out : nullptr, any_zero));
+        max_published = async && max_out && row1 > row0;
+    } else if (p.mode == STEPTH_MODE_RING_FIRST_HIT) {
+        // one group per pixel
+        uint32_t bw = 0, bh = 0;
+        uint32_t lo = 0, hi = 0xFFFFFFFFu;
+        if (p.max_steps < 0x40000000u) {
+            // rows of the additional image the strip's searches can reach: the centres lie in
+            // rows [row0/2, (row1+1)/2], every search stays within max_steps-1 rings of its centre
+            const uint32_t reach = p.max_steps ? p.max_steps - 1u : 0u;
+            const uint32_t c_lo = row0 / 2u, c_hi = (row1 + 1u) / 2u;
+            lo = c_lo > reach ? c_lo - reach : 0u;
+            hi = c_hi + reach + 1u;
+        }
+        // the dense lane = query search (tile_kernels.h); beyond 263 rings the round-1 trio
+        const bool use_tile = tile_search_fits(p.max_steps, add_im->width, add_im->height);
+        if (use_tile)
+            TRY(pack_additional_tiles(e, 1, &d_add, as, add_im->width, add_im->height, bw, bh, lo, hi));
+        else
+            TRY(pack_additional(e, 1, &d_add, as, add_im->width, add_im->height, bw, bh, lo, hi));
 
         RingArgs ra{};
         ra.T = (const uint32_t *)e->T.p;
@@ -932,115 +1021,29 @@ int stepth_depth_from_additional(stepth_engine *e, const stepth_image *main_im,
         ra.max_steps = p.max_steps;
         memcpy(ra.prec, p.precision, 3);
         ra.max_word = e->words;
-
-        PaintArgs pa{};
-        pa.max_word = e->words;
-        pa.max_out = async ? max_out : nullptr;
-        pa.identity = raw_only;
-        pa.out[0] = d_out;
-        pa.ostride = os;
-        pa.w = W;
-        pa.h = H;
-        pa.row_begin = row0;
-        pa.row_end = row1;
-        pa.rp = rp;
-
         const uint32_t rows = row1 - row0;
-        int qmode;
-        const void *d_groups = nullptr;
-        if (groups) {
-            if (n_groups == 0 || n_groups > 0xFFFFFF00ull)
-                return fail(e, STEPTH_ERR_BAD_ARG, "group list of %zu entries", n_groups);
-            if (groups_memory == STEPTH_MEM_DEVICE) {
-                d_groups = groups;
-            } else {
-                TRY(reserve(e, e->stage_groups, n_groups * sizeof(stepth_group)));
-                HIP_TRY(e, hipMemcpyAsync(e->stage_groups.p, groups,
-                                          n_groups * sizeof(stepth_group), hipMemcpyHostToDevice,
-                                          e->stream));
-                d_groups = e->stage_groups.p;
-            }
-            ra.n = (uint32_t)n_groups;
-            TRY(reserve(e, e->queries, (size_t)ra.n * sizeof(Query)));
-            PrepArgs pr{};
-            pr.groups[0] = d_groups;
-            pr.n[0] = ra.n;
-            pr.row_begin = row0;
-            pr.row_end = row1;
-            memcpy(pr.prec, p.precision, 3);
-            pr.out = (Query *)e->queries.p;
-            hipLaunchKernelGGL(prep_list_kernel, dim3((ra.n + 255) / 256), dim3(256), 0, e->stream, pr);
-            HIP_TRY(e, hipGetLastError());
-            ra.queries = pr.out;
-            ra.nq[0] = ra.n;
-            qmode = 1;
-            // groups not in the strip paint nothing; unpainted pixels keep the caller's bytes,
-            // so clear the strip first like ImageBuffer::from_pixel(.., Luma([0])) (:20)
-            if (rows)
-                HIP_TRY(e, hipMemset2DAsync(d_out + (size_t)row0 * os, os, 0, W, rows, e->stream));
-        } else {
-            if (p.tile_w == 0 || p.tile_h == 0)
-                return fail(e, STEPTH_ERR_BAD_ARG, "tile size 0");
-            if (row0 % p.tile_h != 0 || (row1 % p.tile_h != 0 && row1 != H))
-                return fail(e, STEPTH_ERR_BAD_ARG, "row strip [%u,%u) not aligned to tile_h %u",
-                            row0, row1, p.tile_h);
-            const uint32_t gx = (W + p.tile_w - 1) / p.tile_w;
-            const uint32_t gy = (rows + p.tile_h - 1) / p.tile_h;
-            ra.n = gx * gy;
-            pa.tile_w = p.tile_w;
-            pa.tile_h = p.tile_h;
-            pa.gx = gx;
-            if (p.tile_w == 1 && p.tile_h == 1) {
-                ra.main_px[0] = d_main;
-                ra.mstride = ms;
-                ra.mch = main_im->channels;
-                ra.w = W;
-                ra.row0 = row0;
-                ra.row1 = row1;
-                // 2x2 tiles anchored at odd coordinates: tile (tx,ty) = pixels 2tx-1..2tx x
-                // 2ty-1..2ty, all of which have middle (tx,ty)
-                ra.ntx = (W >> 1) + 1u;
-                ra.ty0 = (row0 + 1u) >> 1;
-                uint64_t n_slots = rows ? (uint64_t)ra.ntx * ((row1 >> 1) - ra.ty0 + 1u) * 4u : 0u;
-                ra.rp = rp;
-                if (rp.block) {
-                    // owned blocks b = rem, rem+mod, ... with b*block < H
-                    const uint32_t nb_all = (H + rp.block - 1u) / rp.block;
-                    const uint32_t nb = nb_all > rp.rem ? (nb_all - rp.rem + rp.mod - 1u) / rp.mod : 0u;
-                    n_slots = rows ? (uint64_t)ra.ntx * nb * (rp.block / 2u + 1u) * 4u : 0u;
-                }
-                if (n_slots > 0xFFFFFFFFull && !use_tile)
-                    return fail(e, STEPTH_ERR_BAD_ARG, "%ux%u pixels: too many query slots for one call", W, rows);
-                ra.n_slots = (uint32_t)std::min<uint64_t>(n_slots, 0xFFFFFFFFull);
-                qmode = 0;
-            } else {
-                TRY(reserve(e, e->queries, (size_t)std::max(ra.n, 1u) * sizeof(Query)));
-                PrepArgs pr{};
-                pr.main_px[0] = d_main;
-                pr.mstride = ms;
-                pr.mch = main_im->channels;
-                pr.w = W;
-                pr.h = H;
-                pr.tile_w = p.tile_w;
-                pr.tile_h = p.tile_h;
-                pr.gx = gx;
-                pr.gy = gy;
-                pr.n[0] = ra.n;
-                pr.row_begin = row0;
-                pr.row_end = row1;
-                pr.rp = rp;
-                memcpy(pr.prec, p.precision, 3);
-                pr.out = (Query *)e->queries.p;
-                if (ra.n) {
-                    hipLaunchKernelGGL(prep_tiles_kernel, dim3((ra.n + 255) / 256), dim3(256), 0,
-                                       e->stream, pr);
-                    HIP_TRY(e, hipGetLastError());
-                }
-                ra.queries = pr.out;
-                ra.nq[0] = ra.n;
-                qmode = 1;
-            }
+        ra.n = W * rows;
+        ra.main_px[0] = d_main;
+        ra.mstride = ms;
+        ra.mch = main_im->channels;
+        ra.w = W;
+        ra.row0 = row0;
+        ra.row1 = row1;
+        // (round-1 trio) 2x2 tiles anchored at odd coordinates: tile (tx,ty) = pixels 2tx-1..2tx x
+        // 2ty-1..2ty, all of which have middle (tx,ty)
+        ra.ntx = (W >> 1) + 1u;
+        ra.ty0 = (row0 + 1u) >> 1;
+        uint64_t n_slots = rows ? (uint64_t)ra.ntx * ((row1 >> 1) - ra.ty0 + 1u) * 4u : 0u;
+        ra.rp = rp;
+        if (rp.block) {
+            // owned blocks b = rem, rem+mod, ... with b*block < H
+            const uint32_t nb_all = (H + rp.block - 1u) / rp.block;
+            const uint32_t nb = nb_all > rp.rem ? (nb_all - rp.rem + rp.mod - 1u) / rp.mod : 0u;
+            n_slots = rows ? (uint64_t)ra.ntx * nb * (rp.block / 2u + 1u) * 4u : 0u;
         }
+        if (n_slots > 0xFFFFFFFFull && !use_tile)
+            return fail(e, STEPTH_ERR_BAD_ARG, "%ux%u pixels: too many query slots for one call", W, rows);
+        ra.n_slots = (uint32_t)std::min<uint64_t>(n_slots, 0xFFFFFFFFull);
         TRY(reserve(e, e->raw, std::max<size_t>(ra.n, 4)));
         ra.raw = static_cast<uint8_t *>(e->raw.p);
         if (e->stats_enabled) {
@@ -1050,18 +1053,26 @@ int stepth_depth_from_additional(stepth_engine *e, const stepth_image *main_im,
         if (use_tile)
             TRY(launch_tile(e, ra, 1));
         else
-            TRY(launch_ring(e, ra, qmode));
+            TRY(launch_ring(e, ra, 0));
 
-        pa.raw = ra.raw;
-        pa.groups_list[0] = d_groups;
-        pa.n_list[0] = ra.n;
-        pa.n = ra.n;
-        if (rows && ra.n) {
+        if (rows) {
+            PaintArgs pa{};
+            pa.max_word = e->words;
+            pa.max_out = async ? max_out : nullptr;
+            pa.identity = raw_only;
+            pa.out[0] = d_out;
+            pa.ostride = os;
+            pa.w = W;
+            pa.h = H;
+            pa.row_begin = row0;
+            pa.row_end = row1;
+            pa.rp = rp;
+            pa.tile_w = pa.tile_h = 1;
+            pa.gx = W;
+            pa.raw = ra.raw;
+            pa.n = ra.n;
             max_published = async && max_out;
-            if (groups) {
-                hipLaunchKernelGGL(paint_list_kernel, dim3((ra.n + 3) / 4), dim3(256), 0, e->stream, pa);
-            } else if (qmode == 0 && (W & 3u) == 0 && (os & 3u) == 0 &&
-                       (reinterpret_cast<uintptr_t>(d_out) & 3u) == 0) {
+            if ((W & 3u) == 0 && (os & 3u) == 0 && (reinterpret_cast<uintptr_t>(d_out) & 3u) == 0) {
                 const size_t total = (size_t)rows * (W / 4);
                 const uint32_t blocks = (uint32_t)std::min<size_t>((total + 255) / 256, 2048);
                 hipLaunchKernelGGL(paint_1x1_vec4_kernel, dim3(blocks), dim3(256), 0, e->stream, pa);
@@ -1226,7 +1237,11 @@ static int ring_queries_batch(stepth_engine *e, uint32_t nf, const stepth_image 
         lo = c_lo > reach ? c_lo - reach : 0u;
         hi = c_hi + reach + 1u;
     }
-    TRY(pack_additional(e, nf, d_adds, adds[0].stride, adds[0].width, adds[0].height, bw, bh, lo, hi));
+    const bool use_list = tile_search_fits(p.max_steps, adds[0].width, adds[0].height);
+    if (use_list)
+        TRY(pack_additional_tiles(e, nf, d_adds, adds[0].stride, adds[0].width, adds[0].height, bw, bh, lo, hi));
+    else
+        TRY(pack_additional(e, nf, d_adds, adds[0].stride, adds[0].width, adds[0].height, bw, bh, lo, hi));
 
     RingArgs ra{};
     ra.T = (const uint32_t *)e->T.p;
@@ -1276,12 +1291,40 @@ static int ring_queries_batch(stepth_engine *e, uint32_t nf, const stepth_image 
     TRY(reserve(e, e->queries, (size_t)n_max * nf * sizeof(Query)));
     pr.out = (Query *)e->queries.p;
     const dim3 pgrid((n_max + 255) / 256, nf);
+    const bool sort_queries = d_groups && use_list; // tiles come in row-major order already
+    BinArgs ba{};
+    if (sort_queries) {
+        ba.bins_x = (adds[0].width + 31u) / 32u;
+        ba.bins_y = (adds[0].height + 31u) / 32u;
+        ba.n_bins = ba.bins_x * ba.bins_y + 1u;
+        TRY(reserve(e, e->query_bins, (size_t)ba.n_bins * nf * 4));
+        TRY(reserve(e, e->queries_sorted, (size_t)n_max * nf * sizeof(Query)));
+        TRY(reserve(e, e->query_ids, (size_t)n_max * nf * 4));
+        HIP_TRY(e, hipMemsetAsync(e->query_bins.p, 0, (size_t)ba.n_bins * nf * 4, e->stream));
+        pr.bin_counts = (uint32_t *)e->query_bins.p;
+        pr.bins_x = ba.bins_x;
+        pr.bins_y = ba.bins_y;
+        pr.n_bins = ba.n_bins;
+    }
     if (d_groups)
         hipLaunchKernelGGL(prep_list_kernel, pgrid, dim3(256), 0, e->stream, pr);
     else
         hipLaunchKernelGGL(prep_tiles_kernel, pgrid, dim3(256), 0, e->stream, pr);
-    HIP_TRY(e, hipGetLastError());
     ra.queries = pr.out;
+    if (sort_queries) {
+        ba.in = pr.out;
+        ba.out = (Query *)e->queries_sorted.p;
+        ba.ids = (uint32_t *)e->query_ids.p;
+        ba.bins = pr.bin_counts;
+        ba.q_stride = n_max;
+        for (uint32_t f = 0; f < nf; ++f)
+            ba.n[f] = pr.n[f];
+        hipLaunchKernelGGL(bin_scan_kernel, dim3(nf), dim3(256), 0, e->stream, ba);
+        hipLaunchKernelGGL(bin_scatter_kernel, pgrid, dim3(256), 0, e->stream, ba);
+        ra.queries = ba.out;
+        ra.query_ids = ba.ids;
+    }
+    HIP_TRY(e, hipGetLastError());
     ra.q_stride = n_max;
     for (uint32_t f = 0; f < nf; ++f)
         ra.nq[f] = pr.n[f];
@@ -1295,7 +1338,10 @@ static int ring_queries_batch(stepth_engine *e, uint32_t nf, const stepth_image 
         for (uint32_t f = 0; f < nf; ++f)
             e->stats_groups += pr.n[f];
     }
-    TRY(launch_ring(e, ra, 1, nf));
+    if (use_list)
+        TRY(launch_list(e, ra, nf));
+    else
+        TRY(launch_ring(e, ra, 1, nf));
 
     PaintArgs pa{};
     pa.raw = ra.raw;
@@ -1321,7 +1367,7 @@ static int ring_queries_batch(stepth_engine *e, uint32_t nf, const stepth_image 
         }
         hipLaunchKernelGGL(zero_rows_kernel, dim3((uint32_t)std::min<size_t>(((size_t)rows * W + 255) / 256, 512), nf),
                            dim3(256), 0, e->stream, pa);
-        hipLaunchKernelGGL(paint_list_kernel, dim3((n_max + 3) / 4, nf), dim3(256), 0, e->stream, pa);
+        hipLaunchKernelGGL(paint_list_kernel, dim3((n_max + 15) / 16, nf), dim3(256), 0, e->stream, pa);
     } else {
         pa.tile_w = p.tile_w;
         pa.tile_h = p.tile_h;
@@ -1837,7 +1883,11 @@ int stepth_distance_dot_array_batch(stepth_engine *e, const stepth_image *array,
     size_t as = 0;
     TRY(to_device(e, *array, e->stage_add, d_add, as));
     uint32_t bw = 0, bh = 0;
-    TRY(pack_additional(e, 1, &d_add, as, array->width, array->height, bw, bh));
+    const bool use_list = tile_search_fits(max, array->width, array->height);
+    if (use_list)
+        TRY(pack_additional_tiles(e, 1, &d_add, as, array->width, array->height, bw, bh, 0, 0xFFFFFFFFu));
+    else
+        TRY(pack_additional(e, 1, &d_add, as, array->width, array->height, bw, bh));
 
     std::vector<Query> qs(n);
     for (size_t i = 0; i < n; ++i) {
@@ -1876,7 +1926,10 @@ int stepth_distance_dot_array_batch(stepth_engine *e, const stepth_image *array,
         HIP_TRY(e, hipMemsetAsync(e->stats, 0, kStatsBytes, e->stream));
         e->stats_groups = n;
     }
-    TRY(launch_ring(e, ra, 1));
+    if (use_list)
+        TRY(launch_list(e, ra, 1));
+    else
+        TRY(launch_ring(e, ra, 1));
     HIP_TRY(e, hipMemcpyAsync(dist, ra.raw32, n * 4, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipMemcpyAsync(pos_xy, ra.pos, n * 8, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipMemcpyAsync(found, ra.found, n, hipMemcpyDeviceToHost, e->stream));

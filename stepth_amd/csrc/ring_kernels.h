@@ -158,7 +158,43 @@ struct PrepArgs {
     RowPattern rp;
     uint8_t prec[3];
     Query *out;
+    // optional (group lists): per frame, how many queries fall into each 32x32-cell bin of
+    // search centres (last bin: queries that search nothing) -- the first pass of a counting sort
+    uint32_t *bin_counts;
+    uint32_t bins_x, bins_y, n_bins; // n_bins = bins_x * bins_y + 1
 };
+
+// Group lists arrive in any order, but the per-lane search kernel shares a window of
+// superblocks among the 64 queries of a wave: queries are sorted by the 32x32-cell bin of their
+// search centre (counting sort: count in prep_list_kernel, scan, scatter).
+// bins[key] += 1 for every active lane, one atomic per DISTINCT key of the wave (consecutive
+// groups mostly share a bin, and same-address atomics serialise); returns the lane's slot
+__device__ __forceinline__ uint32_t bin_add(uint32_t *bins, uint32_t key, bool active)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    unsigned long long todo = __builtin_amdgcn_ballot_w64(active);
+    uint32_t slot = 0;
+    while (todo) {
+        const int leader = __ffsll(todo) - 1;
+        const uint32_t lk = (uint32_t)__builtin_amdgcn_readlane((int)key, leader);
+        const unsigned long long same = __builtin_amdgcn_ballot_w64(active && key == lk);
+        uint32_t base = 0;
+        if ((int)lane == leader)
+            base = atomicAdd(bins + lk, (uint32_t)__popcll(same));
+        base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+        if (active && key == lk)
+            slot = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+        todo &= ~same;
+    }
+    return slot;
+}
+
+__device__ __forceinline__ uint32_t query_bin(const Query &q, uint32_t bins_x, uint32_t bins_y)
+{
+    if (q.cx == ~0u)
+        return bins_x * bins_y;
+    return min(q.cy >> 5, bins_y - 1u) * bins_x + min(q.cx >> 5, bins_x - 1u);
+}
 
 struct GroupRec { // == stepth_group
     uint32_t x, y, w, h;
@@ -203,7 +239,7 @@ __global__ __launch_bounds__(256) void prep_list_kernel(PrepArgs a)
 {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x, f = blockIdx.y;
     if (g >= a.n[f])
-        return;
+        return; // (bin_add below works on whatever lanes are left)
     const GroupRec r = reinterpret_cast<const GroupRec *>(a.groups[f])[g];
     Query q;
     if (r.y >= a.row_begin && r.y < a.row_end) {
@@ -214,6 +250,52 @@ __global__ __launch_bounds__(256) void prep_list_kernel(PrepArgs a)
     }
     make_box(r.value, a.prec, q.lo, q.hi);
     a.out[(size_t)f * a.q_stride + g] = q;
+    if (a.bin_counts)
+        (void)bin_add(a.bin_counts + (size_t)f * a.n_bins, query_bin(q, a.bins_x, a.bins_y), true);
+}
+
+struct BinArgs {
+    const Query *in; // unsorted queries, frame f's at in + f * q_stride
+    Query *out;      // sorted by bin
+    uint32_t *ids;   // ids[f * q_stride + k] = index of sorted query k in `in` (= its group)
+    uint32_t *bins;  // per frame n_bins counts -> start offsets (bin_scan) -> fill cursors (scatter)
+    uint32_t q_stride, bins_x, bins_y, n_bins;
+    uint32_t n[kMaxBatch];
+};
+
+// exclusive prefix sum over the bins of one frame (one workgroup per frame)
+__global__ __launch_bounds__(256) void bin_scan_kernel(BinArgs a)
+{
+    __shared__ uint32_t s_part[256];
+    uint32_t *bins = a.bins + (size_t)blockIdx.x * a.n_bins;
+    const uint32_t per = (a.n_bins + 255u) / 256u, lo = threadIdx.x * per, hi = min(lo + per, a.n_bins);
+    uint32_t sum = 0;
+    for (uint32_t i = lo; i < hi; ++i)
+        sum += bins[i];
+    s_part[threadIdx.x] = sum;
+    __syncthreads();
+    uint32_t base = 0;
+    for (uint32_t t = 0; t < threadIdx.x; ++t)
+        base += s_part[t];
+    for (uint32_t i = lo; i < hi; ++i) {
+        const uint32_t c = bins[i];
+        bins[i] = base;
+        base += c;
+    }
+}
+
+__global__ __launch_bounds__(256) void bin_scatter_kernel(BinArgs a)
+{
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x, f = blockIdx.y;
+    const bool active = g < a.n[f];
+    Query q = Query{~0u, ~0u, 0u, 0u};
+    if (active)
+        q = a.in[(size_t)f * a.q_stride + g];
+    const uint32_t at = bin_add(a.bins + (size_t)f * a.n_bins, query_bin(q, a.bins_x, a.bins_y), active);
+    if (active) {
+        a.out[(size_t)f * a.q_stride + at] = q;
+        a.ids[(size_t)f * a.q_stride + at] = g;
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -266,6 +348,7 @@ struct RingArgs {
     uint32_t q_stride;
     uint32_t nq[kMaxBatch];
     uint32_t n; // queries per frame (QMODE 1: the largest nq[f])
+    const uint32_t *query_ids; // optional (ring_list_kernel): queries are sorted, results go to these slots
     uint32_t max_steps;
     uint32_t id_bits; // pending ids: query id in the low id_bits, frame above (32: one frame)
     uint8_t prec[3];
@@ -1012,11 +1095,13 @@ __global__ __launch_bounds__(256) void paint_1x1_vec4_kernel(PaintArgs a)
 // unspecified (the reference's serial collect() lets the later group win).
 __global__ __launch_bounds__(256) void paint_list_kernel(PaintArgs a)
 {
+    // 16 lanes per group: the reference's groups hold a few dozen pixels at most once the image
+    // has >= 2^16 of them (src/depth_image.rs:102), a whole wave per group would mostly idle
     __shared__ uint8_t lut[256];
     const uint32_t f = blockIdx.y;
     build_lut(lut, a.max_word + f, a.identity, a.max_out ? a.max_out + f : nullptr);
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t g = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t sub = threadIdx.x & 15u;
+    const uint32_t g = blockIdx.x * 16u + (threadIdx.x >> 4);
     if (g >= a.n_list[f])
         return;
     const GroupRec r = reinterpret_cast<const GroupRec *>(a.groups_list[f])[g];
@@ -1026,7 +1111,7 @@ __global__ __launch_bounds__(256) void paint_list_kernel(PaintArgs a)
     const uint32_t w = min(r.w, a.w - r.x), h = min(r.h, a.h - r.y);
     const size_t cells = (size_t)w * h;
     uint8_t *out = a.out[f];
-    for (size_t i = lane; i < cells; i += 64u) {
+    for (size_t i = sub; i < cells; i += 16u) {
         const uint32_t yy = r.y + (uint32_t)(i / w), xx = r.x + (uint32_t)(i % w);
         out[(size_t)yy * a.ostride + xx] = v;
     }

@@ -420,6 +420,358 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void ring
 }
 
 // ---------------------------------------------------------------------------------------
+// PASS 1 for PREPARED QUERIES (explicit group lists, uniform tiles larger than one pixel,
+// stepth_distance_dot_array_batch): src/depth_image.rs:112-123 for arbitrary `middle`s.
+//
+// Same lane = query scheme and the same per-lane probes (tile_lane.h) as ring_tile_kernel, but
+// the queries of a wave have nothing in common, so everything is per lane: each lane walks the
+// windows around ITS centre -- first the 7x7 blocks around its centre block, then the
+// superblocks of its window ring by ring around its own superblock -- and reads their bounds
+// with its own (vector) loads.  The wave only shares the loop counters; a lane that does not
+// want the window of an iteration sits it out.  Replaces the round-1 trio ring0 / ring_search /
+// ring_finish (one WAVE per <= 4 queries) for searches of up to 263 rings.
+// ---------------------------------------------------------------------------------------
+struct ListArgs {
+    const uint32_t *T, *TT;
+    const uint2 *LB, *BBp, *SBp;
+    uint32_t wa, ha, bw, bh, bwp, sbwp;
+    uint32_t t_stride, bb_stride, sb_stride;
+    const Query *queries; // frame f's at queries + f * q_stride, nq[f] of them
+    const uint32_t *ids;  // optional: results of query k go to slot ids[k] (queries sorted by bin)
+    uint32_t q_stride;
+    uint32_t nq[kMaxBatch];
+    uint32_t max_steps, pos_bits;
+    uint8_t *raw; // (d as u8) per query, depth_image.rs:121
+    uint32_t raw_stride;
+    uint32_t *raw32, *pos; // optional (single frame): d, winning cell (x, y)
+    uint8_t *found;        // optional: Some / None
+    uint32_t *max_word;
+    unsigned long long *stats;
+};
+
+// eight bound tests of one row of blocks held in vector registers, highest column first
+__device__ __forceinline__ uint32_t test_row_v(uint32_t acc, const uint4 &v0, const uint4 &v1,
+                                               const uint4 &v2, const uint4 &v3, uint32_t lo, uint32_t hi)
+{
+    uint32_t t, u;
+    const uint32_t ng = ~kGuard;
+#define STEPTH_BT(MX, MN)                                                                      \
+    "v_sub_u32 %1, " MX ", %3\n v_sub_u32 %2, %4, " MN "\n v_and_or_b32 %1, %1, %2, %5\n"        \
+    "v_cmp_eq_u32 vcc, -1, %1\n v_addc_co_u32 %0, vcc, %0, %0, vcc\n"
+    asm(STEPTH_BT("%20", "%21") STEPTH_BT("%18", "%19") STEPTH_BT("%16", "%17") STEPTH_BT("%14", "%15")
+            STEPTH_BT("%12", "%13") STEPTH_BT("%10", "%11") STEPTH_BT("%8", "%9") STEPTH_BT("%6", "%7")
+        : "+v"(acc), "=&v"(t), "=&v"(u)
+        : "v"(lo), "v"(hi), "s"(ng), "v"(v0.x), "v"(v0.y), "v"(v0.z), "v"(v0.w), "v"(v1.x), "v"(v1.y),
+          "v"(v1.z), "v"(v1.w), "v"(v2.x), "v"(v2.y), "v"(v2.z), "v"(v2.w), "v"(v3.x), "v"(v3.y),
+          "v"(v3.z), "v"(v3.w)
+        : "vcc");
+#undef STEPTH_BT
+    return acc;
+}
+
+// blocks of the 7x7 window (origin = centre block - 3) in block-rings <= r: bit row*8+col
+constexpr uint64_t kNearLe[4] = {0x0000000008000000ull, 0x0000001C1C1C0000ull,
+                                 0x00003E3E3E3E3E00ull, 0x007F7F7F7F7F7F7Full};
+
+template <bool STATS>
+__global__ __launch_bounds__(256) void ring_list_kernel(ListArgs a)
+{
+    const uint32_t lane = threadIdx.x & 63u, f = blockIdx.y;
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const bool valid = i < a.nq[f];
+    const uint32_t tf = f * a.t_stride;
+    const uint2 *BBf = a.BBp + (size_t)f * a.bb_stride;
+    const uint2 *SBf = a.SBp + (size_t)f * a.sb_stride;
+    const uint32_t pb = a.pos_bits, ring_shift = pb + 2u;
+    Query qq = Query{~0u, ~0u, 0u, 0u};
+    if (valid)
+        qq = a.queries[(size_t)f * a.q_stride + i];
+    LaneQ q;
+    q.qx = (int)qq.cx;
+    q.qy = (int)qq.cy;
+    q.lo = qq.lo;
+    q.hi = qq.hi;
+    q.best = kTileNoKey;
+    q.limit = 0u;
+    uint32_t s_end = 0;
+    unsigned long long n_ring0 = 0, n_tests = 0, n_probed = 0, n_near = 0, n_super = 0;
+    // a centre outside the array ends the search at once (helpers.rs:49-51), cx = ~0: not in the strip
+    const bool inb = valid && qq.cx < a.wa && qq.cy < a.ha && a.max_steps > 0;
+    const int cbx = (int)(qq.cx >> 3), cby = (int)(qq.cy >> 3); // only used when inb
+    if (inb) {
+        const uint32_t cell = a.T[tf + ((uint32_t)cby * a.bw + (uint32_t)cbx) * 64u + ((qq.cy & 7u) << 3) + (qq.cx & 7u)];
+        const uint32_t smax = max(max(qq.cx, a.wa - 1u - qq.cx), max(qq.cy, a.ha - 1u - qq.cy));
+        s_end = min(a.max_steps, smax + 1u);
+        if (cell_in_box(cell, q.lo, q.hi))
+            q.best = 0u;
+        else if (s_end > 1u)
+            q.limit = s_end;
+        if constexpr (STATS)
+            n_ring0 = q.best == 0u;
+    }
+
+    // probes the blocks of `cand` (window origin (bx0, by0)) in the order of their bits
+    auto probe_candidates = [&](uint64_t cur, int bx0, int by0) __attribute__((always_inline)) {
+        while (cur != 0ull) {
+            const int k = __builtin_ctzll(cur);
+            cur &= cur - 1ull;
+            const int bx = bx0 + (k & 7), by = by0 + (k >> 3);
+            const int x0 = bx * 8 - q.qx, y0 = by * 8 - q.qy;
+            // (the dmin test also keeps stale bounds of unpacked rows from being probed)
+            if ((uint32_t)square_dmin(x0, y0, 8) < q.limit) {
+                const uint32_t boff = tf + ((uint32_t)by * a.bw + (uint32_t)bx) * 64u;
+                const uint32_t nl = probe_block(q, x0, y0, pb, a.T + boff, a.TT + boff,
+                                                reinterpret_cast<const uint32_t *>(a.LB) + (boff >> 1));
+                if constexpr (STATS) {
+                    ++n_probed;
+                    n_tests += 8u * nl;
+                }
+            }
+        }
+    };
+
+    if (__builtin_amdgcn_ballot_w64(q.limit != 0u)) {
+        // ---- the 7x7 blocks around the lane's own centre block (block-rings 0..3) ----
+        if (q.limit != 0u) {
+            if constexpr (STATS)
+                ++n_near;
+            uint32_t m_lo = 0, m_hi = 0; // bit row*8+col
+            const uint2 *win = BBf + (size_t)(cby - 3 + kPadB) * a.bwp + (size_t)(cbx - 3 + kPadB);
+#pragma unroll
+            for (int row = 6; row >= 4; --row) {
+                const uint4 *rp4 = reinterpret_cast<const uint4 *>(win + (size_t)row * a.bwp);
+                m_hi = test_row_v(m_hi, rp4[0], rp4[1], rp4[2], rp4[3], q.lo, q.hi);
+            }
+#pragma unroll
+            for (int row = 3; row >= 0; --row) {
+                const uint4 *rp4 = reinterpret_cast<const uint4 *>(win + (size_t)row * a.bwp);
+                m_lo = test_row_v(m_lo, rp4[0], rp4[1], rp4[2], rp4[3], q.lo, q.hi);
+            }
+            if constexpr (STATS)
+                n_tests += 56u;
+            const uint64_t cand = (((uint64_t)m_hi << 32) | m_lo) & kNearLe[3];
+            for (int ps = 0; ps < 4; ++ps) {
+                if (8 * (ps - 1) + 1 >= (int)q.limit)
+                    break;
+                probe_candidates(cand & kNearLe[ps] & ~(ps ? kNearLe[ps - 1] : 0ull), cbx - 3, cby - 3);
+            }
+            // settled: best ring <= 24, or nothing beyond ring 24 to search
+            if (s_end <= 25u || (q.best != kTileNoKey && (q.best >> ring_shift) <= 24u))
+                q.limit = 0u;
+        }
+    }
+
+    if (__builtin_amdgcn_ballot_w64(q.limit != 0u)) {
+        // ---- far phase.  The lanes still searching share what they can: the bounding box of
+        // their centres gives ONE window of superblocks for the wave, surveyed and visited
+        // nearest first like in ring_tile_kernel (bounds by scalar loads, every lane against its
+        // own box and its own distance).  Only when the queries of a wave are spread so far
+        // apart that the window does not fit the slots does each lane walk its own window.
+        const int R = (int)a.max_steps - 1;
+        const bool far = q.limit != 0u;
+        const int wx_lo = (int)wave_min_dpp(far ? (uint32_t)q.qx : 0x7fffffffu);
+        const int wy_lo = (int)wave_min_dpp(far ? (uint32_t)q.qy : 0x7fffffffu);
+        const int wx_hi = (int)wave_max_dpp(far ? (uint32_t)q.qx : 0u);
+        const int wy_hi = (int)wave_max_dpp(far ? (uint32_t)q.qy : 0u);
+        const int sx0 = max(wx_lo - R, 0) >> 6, sy0 = max(wy_lo - R, 0) >> 6;
+        const int sx1 = min(wx_hi + R, (int)a.wa - 1) >> 6, sy1 = min(wy_hi + R, (int)a.ha - 1) >> 6;
+        const int nsx = sx1 - sx0 + 1, nsy = sy1 - sy0 + 1;
+        if (nsx <= 10 && nsy <= 12) {
+            // middle of the box orders the visits; a lane's own distance differs by <= tol
+            const int mx = (wx_lo + wx_hi) >> 1, my = (wy_lo + wy_hi) >> 1;
+            const uint32_t tol = (uint32_t)max(wx_hi - mx, wy_hi - my) + 1u;
+            uint32_t skey0 = kTileNoKey, skey1 = kTileNoKey, skey2 = kTileNoKey; // slot ty*16+tx
+            for (int ty = 0; ty < nsy; ++ty) {
+                const int sy = sy0 + ty;
+                const uint4 *sb4 = reinterpret_cast<const uint4 *>(SBf + (size_t)sy * a.sbwp + sx0);
+                const uint4 g0 = sb4[0], g1 = sb4[1], g2 = sb4[2], g3 = sb4[3], g4 = sb4[4];
+                const int ay = (sy << 6) - q.qy;
+                const int dsy = max(max(ay, -63 - ay), 0);
+                const uint32_t sbv[20] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w, g2.x, g2.y,
+                                          g2.z, g2.w, g3.x, g3.y, g3.z, g3.w, g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+                for (int tx = 0; tx < 10; ++tx) {
+                    if (tx >= nsx)
+                        break;
+                    const int ax = ((sx0 + tx) << 6) - q.qx;
+                    const uint32_t dS = (uint32_t)max(max(max(ax, -63 - ax), 0), dsy);
+                    const bool w = dS < q.limit && box_meets(sbv[2 * tx], sbv[2 * tx + 1], q.lo, q.hi);
+                    if constexpr (STATS)
+                        n_tests += q.limit != 0u;
+                    if (__builtin_amdgcn_ballot_w64(w)) {
+                        const int rx = ((sx0 + tx) << 6) - mx, ry = (sy << 6) - my;
+                        const uint32_t dref = (uint32_t)max(max(max(rx, -63 - rx), max(ry, -63 - ry)), 0);
+                        const uint32_t t = (uint32_t)(ty * 16 + tx);
+                        const uint32_t key = (dref << 8) | t;
+                        if (lane == (t & 63u)) {
+                            if (t < 64u)
+                                skey0 = key;
+                            else if (t < 128u)
+                                skey1 = key;
+                            else
+                                skey2 = key;
+                        }
+                    }
+                }
+            }
+            for (;;) {
+                const uint32_t pick = wave_min_dpp(min(min(skey0, skey1), skey2));
+                if (pick == kTileNoKey || (pick >> 8) >= wave_max_dpp(q.limit) + tol)
+                    break;
+                skey0 = skey0 == pick ? kTileNoKey : skey0;
+                skey1 = skey1 == pick ? kTileNoKey : skey1;
+                skey2 = skey2 == pick ? kTileNoKey : skey2;
+                const int sx = sx0 + (int)(pick & 15u), sy = sy0 + (int)((pick >> 4) & 15u);
+                const uint2 sb = SBf[(size_t)sy * a.sbwp + sx];
+                const int ax = (sx << 6) - q.qx, ay = (sy << 6) - q.qy;
+                const uint32_t dS = (uint32_t)max(max(max(ax, -63 - ax), max(ay, -63 - ay)), 0);
+                const bool want = dS < q.limit && box_meets(sb.x, sb.y, q.lo, q.hi);
+                if (!__builtin_amdgcn_ballot_w64(want))
+                    continue;
+                if constexpr (STATS)
+                    n_super += want;
+                const int bx0 = sx * 8, by0 = sy * 8;
+                // bounds of the superblock's 64 blocks: rows and half rows beyond every lane's
+                // limit (distances from the box of the wave's centres) are skipped
+                const uint32_t wlim = wave_max_dpp(want ? q.limit : 0u);
+                uint32_t m_lo = 0, m_hi = 0;
+                const int cx_l = bx0 * 8 - wx_hi, cx_r = wx_lo - (bx0 * 8 + 31); // cols 0..3
+                const bool need_l = max(max(cx_l, cx_r), 0) < (int)wlim;
+                const bool need_h = max(max(cx_l + 32, cx_r - 32), 0) < (int)wlim; // cols 4..7
+                const uint2 *win = BBf + (size_t)(by0 + kPadB) * a.bwp + (size_t)(bx0 + kPadB);
+                auto do_row = [&](uint32_t acc, int row) __attribute__((always_inline)) -> uint32_t {
+                    const int ry0 = (by0 + row) * 8 - wy_hi, ry1 = wy_lo - ((by0 + row) * 8 + 7);
+                    if (max(max(ry0, ry1), 0) >= (int)wlim)
+                        return acc << 8;
+                    const uint4 *rp4 = reinterpret_cast<const uint4 *>(win + (size_t)row * a.bwp);
+                    if (need_h) {
+                        const uint4 v2 = rp4[2], v3 = rp4[3];
+                        acc = test_half_row(acc, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w, q.lo, q.hi);
+                    } else {
+                        acc <<= 4;
+                    }
+                    if (need_l) {
+                        const uint4 v0 = rp4[0], v1 = rp4[1];
+                        acc = test_half_row(acc, v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, q.lo, q.hi);
+                    } else {
+                        acc <<= 4;
+                    }
+                    return acc;
+                };
+#pragma unroll
+                for (int row = 7; row >= 4; --row)
+                    m_hi = do_row(m_hi, row);
+#pragma unroll
+                for (int row = 3; row >= 0; --row)
+                    m_lo = do_row(m_lo, row);
+                if constexpr (STATS)
+                    n_tests += want ? 64u : 0u;
+                if (want) // the lane's own 7x7 window did block-rings 0..3 around ITS centre block
+                    probe_candidates((((uint64_t)m_hi << 32) | m_lo) & ~window_le_mask(bx0, by0, cbx, cby, 3), bx0, by0);
+            }
+        } else {
+            // ---- spread-out wave: every lane walks the superblocks of its own window, ring by
+            // ring around its own superblock (the wave shares only the loop counters) ----
+            const int lx0 = max(q.qx - R, 0) >> 6, ly0 = max(q.qy - R, 0) >> 6;
+            const int lx1 = min(q.qx + R, (int)a.wa - 1) >> 6, ly1 = min(q.qy + R, (int)a.ha - 1) >> 6;
+            const int scx = q.qx >> 6, scy = q.qy >> 6;
+            for (int ring = 0, t = 0;; ++t) {
+                const int n_in_ring = ring == 0 ? 1 : 8 * ring;
+                if (t >= n_in_ring) {
+                    t = 0;
+                    ++ring;
+                }
+                // a superblock of ring r lies at least 64 (r - 1) + 1 rings away
+                const int lb = ring == 0 ? 0 : 64 * (ring - 1) + 1;
+                if (!__builtin_amdgcn_ballot_w64(q.limit != 0u && lb < (int)q.limit))
+                    break;
+                int dx = 0, dy = 0;
+                if (ring > 0) {
+                    const int side = t / (2 * ring), o = t - side * 2 * ring;
+                    dx = side == 0 ? -ring + o : side == 1 ? ring : side == 2 ? ring - o : -ring;
+                    dy = side == 0 ? -ring : side == 1 ? -ring + o : side == 2 ? ring : ring - o;
+                }
+                const int sx = scx + dx, sy = scy + dy;
+                const bool inwin = q.limit != 0u && sx >= lx0 && sx <= lx1 && sy >= ly0 && sy <= ly1;
+                uint2 sb = make_uint2(0u, 0u);
+                if (inwin)
+                    sb = SBf[(size_t)sy * a.sbwp + sx];
+                const int ax = (sx << 6) - q.qx, ay = (sy << 6) - q.qy;
+                const uint32_t dS = (uint32_t)max(max(max(ax, -63 - ax), max(ay, -63 - ay)), 0);
+                const bool want = inwin && dS < q.limit && box_meets(sb.x, sb.y, q.lo, q.hi);
+                if constexpr (STATS)
+                    n_tests += inwin;
+                if (!want)
+                    continue;
+                if constexpr (STATS)
+                    ++n_super;
+                const int bx0 = sx * 8, by0 = sy * 8;
+                uint32_t m_lo = 0, m_hi = 0;
+                const uint2 *win = BBf + (size_t)(by0 + kPadB) * a.bwp + (size_t)(bx0 + kPadB);
+#pragma unroll 1
+                for (int row = 7; row >= 4; --row) {
+                    const uint4 *rp4 = reinterpret_cast<const uint4 *>(win + (size_t)row * a.bwp);
+                    m_hi = test_row_v(m_hi, rp4[0], rp4[1], rp4[2], rp4[3], q.lo, q.hi);
+                }
+#pragma unroll 1
+                for (int row = 3; row >= 0; --row) {
+                    const uint4 *rp4 = reinterpret_cast<const uint4 *>(win + (size_t)row * a.bwp);
+                    m_lo = test_row_v(m_lo, rp4[0], rp4[1], rp4[2], rp4[3], q.lo, q.hi);
+                }
+                if constexpr (STATS)
+                    n_tests += 64u;
+                probe_candidates((((uint64_t)m_hi << 32) | m_lo) & ~window_le_mask(bx0, by0, cbx, cby, 3), bx0, by0);
+            }
+        }
+    }
+
+    // ---- distance, store, max (depth_image.rs:118-124) ----
+    uint32_t d = 0;
+    int ddx = 0, ddy = 0;
+    const bool fnd = q.best != kTileNoKey;
+    if (fnd && q.best != 0u) {
+        const int s = (int)(q.best >> (pb + 2u)), side = (int)((q.best >> pb) & 3u);
+        const int off = (int)(q.best & ((1u << pb) - 1u)) - s;
+        ddx = side < 2 ? off : side == 2 ? s : -s;
+        ddy = side == 0 ? s : side == 1 ? -s : off;
+        d = isqrt_floor((uint32_t)(ddx * ddx + ddy * ddy));
+    }
+    if (valid) {
+        const uint32_t o = a.ids ? a.ids[(size_t)f * a.q_stride + i] : i;
+        a.raw[(size_t)f * a.raw_stride + o] = (uint8_t)(d & 0xffu); // `d as u8` wraps
+        if (a.raw32)
+            a.raw32[o] = d;
+        if (a.pos) {
+            a.pos[2 * (size_t)o] = fnd ? (uint32_t)(q.qx + ddx) : 0u;
+            a.pos[2 * (size_t)o + 1] = fnd ? (uint32_t)(q.qy + ddy) : 0u;
+        }
+        if (a.found)
+            a.found[o] = fnd ? 1 : 0;
+    }
+    const uint32_t wmax = wave_max_dpp(d & 0xffu);
+    if (lane == 0 && wmax > __hip_atomic_load(a.max_word + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        atomicMax(a.max_word + f, wmax);
+    if constexpr (STATS) {
+        unsigned long long v0 = n_ring0, v1 = n_tests, v2 = n_near, v4 = n_super, v5 = n_probed;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            v0 += __shfl_xor(v0, o, 64);
+            v1 += __shfl_xor(v1, o, 64);
+            v2 += __shfl_xor(v2, o, 64);
+            v4 += __shfl_xor(v4, o, 64);
+            v5 += __shfl_xor(v5, o, 64);
+        }
+        if (lane == 0) {
+            atomicAdd(&a.stats[0], v0);
+            atomicAdd(&a.stats[1], v1);
+            atomicAdd(&a.stats[2], v2);
+            atomicAdd(&a.stats[4], v4);
+            atomicAdd(&a.stats[5], v5);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // pack for the dense search: RGB8 [Ha][Wa] -> T, TT (cells, row- and column-major inside
 // the 8x8 block) and the padded block bounds BBp.  One wave per block.  Replaces
 // disage::converters::raw_rgb + pixels_to_array (src/depth_image.rs:97-100).
