@@ -427,7 +427,10 @@ int launch_list(stepth_engine *e, const RingArgs &ra, uint32_t n_frames)
     la.found = ra.found;
     la.max_word = ra.max_word;
     la.stats = e->stats_enabled ? e->stats : nullptr;
-    const dim3 grid((ra.n + 255u) / 256u, n_frames), block(256);
+    // few queries (one frame's group list, a thin strip): fewer queries per wave, more waves
+    const uint64_t total = (uint64_t)ra.n * n_frames;
+    la.lanes = total >= (1u << 18) ? 64u : total >= (1u << 16) ? 32u : 16u;
+    const dim3 grid((ra.n + 4u * la.lanes - 1u) / (4u * la.lanes), n_frames), block(256);
     {
         KernelTimer t(e);
         if (e->stats_enabled)

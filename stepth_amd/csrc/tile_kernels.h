@@ -440,6 +440,7 @@ struct ListArgs {
     const uint32_t *ids;  // optional: results of query k go to slot ids[k] (queries sorted by bin)
     uint32_t q_stride;
     uint32_t nq[kMaxBatch];
+    uint32_t lanes; // queries per wave: 64, or fewer for small launches
     uint32_t max_steps, pos_bits;
     uint8_t *raw; // (d as u8) per query, depth_image.rs:121
     uint32_t raw_stride;
@@ -477,8 +478,11 @@ template <bool STATS>
 __global__ __launch_bounds__(256) void ring_list_kernel(ListArgs a)
 {
     const uint32_t lane = threadIdx.x & 63u, f = blockIdx.y;
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    const bool valid = i < a.nq[f];
+    // a wave takes `lanes` (16, 32 or 64) consecutive queries: a small launch is bound by the
+    // latency of its slowest wave, not by issue slots, and a wave of fewer queries has fewer
+    // windows to sit through
+    const uint32_t i = (blockIdx.x * 4u + (threadIdx.x >> 6)) * a.lanes + lane;
+    const bool valid = lane < a.lanes && i < a.nq[f];
     const uint32_t tf = f * a.t_stride;
     const uint2 *BBf = a.BBp + (size_t)f * a.bb_stride;
     const uint2 *SBf = a.SBp + (size_t)f * a.sb_stride;
