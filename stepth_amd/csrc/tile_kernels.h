@@ -331,6 +331,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void ring
                 if (8 * (r - 1) + 1 >= (int)wlim)
                     break; // (wlim: the lanes' largest limit when the step began)
                 if (8 * (r - 1) + 1 >= (int)q.limit)
+                    cand = 0ull; // this lane is through with the window
+                if (!__builtin_amdgcn_ballot_w64((cand & ~(le & ~cur)) != 0ull))
+                    break; // no lane has a candidate in this or a later block-ring
+                if (8 * (r - 1) + 1 >= (int)q.limit)
                     cur = 0ull;
                 if (!__builtin_amdgcn_ballot_w64(cur != 0ull))
                     continue;
