@@ -13,7 +13,9 @@
 //
 //   workgroup = one 8x8 block of search centres of one frame = 16x16 main-image pixels
 //               (the four pixels 2cx-1..2cx x 2cy-1..2cy share the centre (cx,cy),
-//               depth_image.rs:114-117 with a 1x1 group); wave = 8x2 centres x 4 pixels.
+//               depth_image.rs:114-117 with a 1x1 group); wave = 4x4 centres x 4 pixels (a
+//               square patch: its lanes look for similar colours in similar places; 8x2
+//               centres measured 3 % slower on the bench frames).
 //   All 64 queries of a wave have their centre in the same 8x8-cell block of the additional
 //   image, so the wave walks ONE sequence of blocks: their bounds arrive by scalar loads
 //   (s_load_dwordx16 = a row of 8 blocks) and each lane tests them against its own colour box
@@ -144,7 +146,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void ring
 
     // ---- the lane's query ----
     const uint32_t c = lane >> 2, m = lane & 3u;
-    const uint32_t cx = (uint32_t)CBX * 8u + (c & 7u), cy = (uint32_t)CBY * 8u + wv * 2u + (c >> 3);
+    const uint32_t cx = (uint32_t)CBX * 8u + (wv & 1u) * 4u + (c & 3u), cy = (uint32_t)CBY * 8u + (wv >> 1) * 4u + (c >> 2);
     const uint32_t x = 2u * cx - 1u + (m & 1u), y = 2u * cy - 1u + (m >> 1); // may wrap: invalid
     const bool valid = x < a.w && y >= a.row0 && y < a.row1 && a.rp.owns(y);
     LaneQ q;
@@ -181,9 +183,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void ring
         // superblock window of the wave (far phase): every lane's window of radius
         // max_steps-1 lies inside it
         const int R = (int)a.max_steps - 1;
-        const int wx0 = CBX * 8, wy0 = CBY * 8 + (int)wv * 2;
+        const int wx0 = CBX * 8 + (int)(wv & 1u) * 4, wy0 = CBY * 8 + (int)(wv >> 1) * 4;
         const int sx0 = max(wx0 - R, 0) >> 6, sy0 = max(wy0 - R, 0) >> 6;
-        const int sx1 = min(wx0 + 7 + R, (int)a.wa - 1) >> 6, sy1 = min(wy0 + 1 + R, (int)a.ha - 1) >> 6;
+        const int sx1 = min(wx0 + 3 + R, (int)a.wa - 1) >> 6, sy1 = min(wy0 + 3 + R, (int)a.ha - 1) >> 6;
         const int nsx = sx1 - sx0 + 1, nsy = sy1 - sy0 + 1; // <= 10 each for max_steps <= 258
         uint32_t skey0 = kTileNoKey, skey1 = kTileNoKey, skey2 = kTileNoKey; // slot ty*16+tx
 
@@ -236,7 +238,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void ring
                                 n_tests += q.limit != 0u;
                             if (__builtin_amdgcn_ballot_w64(w)) {
                                 // distance from the middle of the wave's centres orders the visits
-                                const int rx = ((sx0 + tx) << 6) - (wx0 + 4), ry = (sy << 6) - (wy0 + 1);
+                                const int rx = ((sx0 + tx) << 6) - (wx0 + 2), ry = (sy << 6) - (wy0 + 2);
                                 const uint32_t dref = (uint32_t)max(max(max(rx, -63 - rx), max(ry, -63 - ry)), 0);
                                 const uint32_t t = (uint32_t)(ty * 16 + tx);
                                 const uint32_t key = (dref << 8) | t;
@@ -254,10 +256,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void ring
                     pc_survey += STEPTH_TICK() - pc_s0;
                 }
                 // nearest superblock some lane may still want.  Slots come in the order of their
-                // distance from the middle of the wave's centres, which is within 4 rings of
-                // every lane's own distance: past the largest limit + 4 nothing is left.
+                // distance from the middle of the wave's centres, which is within 2 rings of
+                // every lane's own distance: past the largest limit + 2 nothing is left.
                 const uint32_t pick = wave_min_dpp(min(min(skey0, skey1), skey2));
-                if (pick == kTileNoKey || (pick >> 8) >= wave_max_dpp(q.limit) + 4u)
+                if (pick == kTileNoKey || (pick >> 8) >= wave_max_dpp(q.limit) + 2u)
                     break;
                 skey0 = skey0 == pick ? kTileNoKey : skey0;
                 skey1 = skey1 == pick ? kTileNoKey : skey1;
@@ -280,17 +282,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void ring
 
             // ---- bounds of the window's 8x8 blocks against the lane's box ----
             // Rows and half rows of blocks that lie beyond every lane's limit are skipped
-            // (wave-uniform: distances from the wave's 8x2 centres).
+            // (wave-uniform: distances from the wave's 4x4 centres).
             uint32_t m_lo = 0, m_hi = 0; // bit row*8+col
             [[maybe_unused]] const unsigned long long pc_b0 = STEPTH_TICK();
             const uint32_t wlim = wave_max_dpp(want ? q.limit : 0u);
             {
-                const int cx_l = bx0 * 8 - (wx0 + 7), cx_r = wx0 - (bx0 * 8 + 31); // cols 0..3
+                const int cx_l = bx0 * 8 - (wx0 + 3), cx_r = wx0 - (bx0 * 8 + 31); // cols 0..3
                 const bool need_l = max(max(cx_l, cx_r), 0) < (int)wlim;
                 const bool need_h = max(max(cx_l + 32, cx_r - 32), 0) < (int)wlim;   // cols 4..7
                 const uint2 *win = BBf + (size_t)(by0 + kPadB) * a.bwp + (size_t)(bx0 + kPadB);
                 auto do_row = [&](uint32_t acc, int row) __attribute__((always_inline)) -> uint32_t {
-                    const int ry0 = (by0 + row) * 8 - (wy0 + 1), ry1 = wy0 - ((by0 + row) * 8 + 7);
+                    const int ry0 = (by0 + row) * 8 - (wy0 + 3), ry1 = wy0 - ((by0 + row) * 8 + 7);
                     if (max(max(ry0, ry1), 0) >= (int)wlim || (it == 0 && row == 7))
                         return acc << 8;
                     const uint4 *rp4 = reinterpret_cast<const uint4 *>(win + (size_t)row * a.bwp);

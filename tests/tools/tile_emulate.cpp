@@ -111,7 +111,7 @@ extern "C" int tile_emulate(const uint8_t *main_px, uint32_t W, uint32_t H, uint
                 bool any = false;
                 for (uint32_t lane = 0; lane < 64; ++lane) {
                     const uint32_t c = lane >> 2, m = lane & 3;
-                    const uint32_t cx = CBX * 8u + (c & 7), cy = CBY * 8u + wv * 2 + (c >> 3);
+                    const uint32_t cx = CBX * 8u + (wv & 1) * 4 + (c & 3), cy = CBY * 8u + (wv >> 1) * 4 + (c >> 2);
                     const uint32_t x = 2 * cx - 1 + (m & 1), y = 2 * cy - 1 + (m >> 1);
                     valid[lane] = x < W && y >= row0 && y < row1;
                     px[lane] = x;
@@ -141,10 +141,10 @@ extern "C" int tile_emulate(const uint8_t *main_px, uint32_t W, uint32_t H, uint
                 }
                 if (any) {
                     const int R = (int)max_steps - 1;
-                    const int wx0 = CBX * 8, wy0 = CBY * 8 + (int)wv * 2;
+                    const int wx0 = CBX * 8 + (int)(wv & 1) * 4, wy0 = CBY * 8 + (int)(wv >> 1) * 4;
                     const int sx0 = std::max(wx0 - R, 0) >> 6, sy0 = std::max(wy0 - R, 0) >> 6;
-                    const int sx1 = std::min(wx0 + 7 + R, (int)wa - 1) >> 6;
-                    const int sy1 = std::min(wy0 + 1 + R, (int)ha - 1) >> 6;
+                    const int sx1 = std::min(wx0 + 3 + R, (int)wa - 1) >> 6;
+                    const int sy1 = std::min(wy0 + 3 + R, (int)ha - 1) >> 6;
                     const int nsx = sx1 - sx0 + 1, nsy = sy1 - sy0 + 1;
                     if (nsx > 16 || nsy > 12)
                         return -1; // the kernel's slots would not fit
@@ -182,7 +182,7 @@ extern "C" int tile_emulate(const uint8_t *main_px, uint32_t W, uint32_t H, uint
                                             anyw |= dS < q[l].limit && box_meets(sb.x, sb.y, q[l].lo, q[l].hi);
                                         }
                                         if (anyw) {
-                                            const uint32_t dref = (uint32_t)square_dmin((sx << 6) - (wx0 + 4), (sy << 6) - (wy0 + 1), 64);
+                                            const uint32_t dref = (uint32_t)square_dmin((sx << 6) - (wx0 + 2), (sy << 6) - (wy0 + 2), 64);
                                             skeys.push_back((dref << 8) | (uint32_t)(ty * 16 + tx));
                                         }
                                     }
