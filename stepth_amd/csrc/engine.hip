@@ -57,7 +57,6 @@ struct stepth_engine {
     uint32_t bbp_layout[3] = {0, 0, 0}; // bw, bh, frames the zero border of BBp was laid out for
     DevBuf stage_main, stage_add, stage_out, stage_groups;
     DevBuf queries_sorted, query_ids, query_bins; // group lists sorted by search-centre bin
-    DevBuf defer_q, defer_ids, defer_counts;      // pixels ring_quad_kernel hands to ring_list_kernel
     DevBuf queries, raw, aux32, aux_pos, aux_found, pending, pending_rec, pending_key;
     DevBuf sad_left, sad_right, gauss_tmp, gauss_io;
     DevBuf zone_counts, zone_tables; // depth_split: 256 counts and one ZoneTable per frame
@@ -357,10 +356,10 @@ int launch_tile(stepth_engine *e, const RingArgs &ra, uint32_t n_frames)
     ta.cbx_n = ((ra.w >> 1) + 8u) >> 3;
     ta.cby0 = ((ra.row0 + 1u) >> 1) >> 3;
     ta.cby_n = ((ra.row1 >> 1) >> 3) - ta.cby0 + 1u;
-    const uint64_t n_wg = (uint64_t)ta.cbx_n * ta.cby_n * n_frames;
+    ta.n_rows = ta.cby_n * n_frames;
+    const uint64_t n_wg = (uint64_t)((ta.n_rows + 7u) / 8u) * 8u * ta.cbx_n; // rows dealt to 8 XCDs
     if (n_wg > 0x7FFFFFF0ull)
         return fail(e, STEPTH_ERR_BAD_ARG, "too many centre blocks in one launch");
-    ta.n_wg = (uint32_t)n_wg;
     // a search never leaves the array: more steps than its longer side change nothing
     ta.max_steps = std::min(ra.max_steps, std::max(ra.wa, ra.ha));
     {
@@ -375,73 +374,14 @@ int launch_tile(stepth_engine *e, const RingArgs &ra, uint32_t n_frames)
     ta.raw_stride = (uint32_t)(((size_t)ra.n + 3u) & ~(size_t)3u);
     ta.max_word = ra.max_word;
     ta.stats = e->stats_enabled ? e->stats : nullptr;
-#ifndef STEPTH_LANE_IS_CENTRE // (-DSTEPTH_LANE_IS_CENTRE: the experimental lane = centre kernel)
-    const dim3 grid((ta.n_wg + 7u) & ~7u), block(256);
+    const dim3 grid((uint32_t)n_wg), block(256);
     {
-        KernelTimer t(e);
+        KernelTimer t(e); // the dominant kernel (bench.py's roofline leg)
         if (e->stats_enabled)
             hipLaunchKernelGGL(ring_tile_kernel<true>, grid, block, 0, e->stream, ta);
         else
             hipLaunchKernelGGL(ring_tile_kernel<false>, grid, block, 0, e->stream, ta);
     }
-#else
-    // a workgroup = 2x2 centre blocks, one per wave
-    ta.n_wg = ((ta.cbx_n + 1u) >> 1) * ((ta.cby_n + 1u) >> 1) * n_frames;
-    // pixels on colour edges are handed to ring_list_kernel (tile_kernels.h); any pixel may be
-    const uint32_t n_queues = n_frames * kDeferParts;
-    const size_t cap = (size_t)((ta.n_wg / n_frames + kDeferParts - 1u) / kDeferParts) * 1024u; // per queue
-    TRY(reserve(e, e->defer_q, cap * n_queues * sizeof(Query)));
-    TRY(reserve(e, e->defer_ids, cap * n_queues * 4));
-    TRY(reserve(e, e->defer_counts, (size_t)n_queues * kDeferPad * 4));
-    HIP_TRY(e, hipMemsetAsync(e->defer_counts.p, 0, (size_t)n_queues * kDeferPad * 4, e->stream));
-    ta.defer_q = (Query *)e->defer_q.p;
-    ta.defer_ids = (uint32_t *)e->defer_ids.p;
-    ta.defer_count = (uint32_t *)e->defer_counts.p;
-    ta.defer_stride = (uint32_t)cap;
-    const dim3 grid((ta.n_wg + 7u) & ~7u), block(256);
-    {
-        KernelTimer t(e); // the dominant kernel (bench.py's roofline leg)
-        if (e->stats_enabled)
-            hipLaunchKernelGGL(ring_quad_kernel<true>, grid, block, 0, e->stream, ta);
-        else
-            hipLaunchKernelGGL(ring_quad_kernel<false>, grid, block, 0, e->stream, ta);
-    }
-    {
-        ListArgs la{};
-        la.T = ta.T;
-        la.TT = ta.TT;
-        la.LB = ta.LB;
-        la.BBp = ta.BBp;
-        la.SBp = ta.SBp;
-        la.wa = ta.wa;
-        la.ha = ta.ha;
-        la.bw = ta.bw;
-        la.bh = ta.bh;
-        la.bwp = ta.bwp;
-        la.sbwp = ta.sbwp;
-        la.t_stride = ta.t_stride;
-        la.bb_stride = ta.bb_stride;
-        la.sb_stride = ta.sb_stride;
-        la.queries = ta.defer_q;
-        la.ids = ta.defer_ids;
-        la.q_stride = ta.defer_stride;
-        la.nq_dev = ta.defer_count;
-        la.parts = kDeferParts;
-        la.lanes = 64u;
-        la.max_steps = ta.max_steps;
-        la.pos_bits = ta.pos_bits;
-        la.raw = ta.raw;
-        la.raw_stride = ta.raw_stride;
-        la.max_word = ta.max_word;
-        la.stats = ta.stats;
-        // the counts are on the device: a grid for the most there can be, idle workgroups leave at once
-        const dim3 lgrid((uint32_t)((cap + 255u) / 256u), n_queues);
-        if (e->stats_enabled)
-            hipLaunchKernelGGL(ring_list_kernel<true>, lgrid, block, 0, e->stream, la);
-        else
-            hipLaunchKernelGGL(ring_list_kernel<false>, lgrid, block, 0, e->stream, la);
-    }
-#endif
     HIP_TRY(e, hipGetLastError());
     return STEPTH_OK;
 }
@@ -805,7 +745,7 @@ void stepth_engine_destroy(stepth_engine *e)
     (void)hipSetDevice(e->device);
     (void)hipStreamSynchronize(e->stream);
     for (DevBuf *b : {&e->T, &e->BB, &e->SB, &e->TT, &e->LB, &e->BBp, &e->SBp, &e->spiral, &e->stage_main, &e->stage_add, &e->stage_out,
-                      &e->stage_groups, &e->queries, &e->queries_sorted, &e->query_ids, &e->query_bins, &e->defer_q, &e->defer_ids, &e->defer_counts, &e->raw, &e->aux32, &e->aux_pos,
+                      &e->stage_groups, &e->queries, &e->queries_sorted, &e->query_ids, &e->query_bins, &e->raw, &e->aux32, &e->aux_pos,
                       &e->aux_found, &e->pending, &e->pending_rec, &e->pending_key, &e->sad_left, &e->sad_right, &e->gauss_tmp, &e->gauss_io,
                       &e->zone_counts, &e->zone_tables, &e->pipe_main[0], &e->pipe_main[1],
                       &e->pipe_add[0], &e->pipe_add[1], &e->pipe_out[0], &e->pipe_out[1], &e->pipe_max, &e->group_out,

@@ -62,25 +62,14 @@ struct TileArgs {
     size_t mstride;
     uint32_t mch, w, row0, row1;
     RowPattern rp;
-    uint32_t cbx_n, cby0, cby_n, n_wg; // centre blocks of the strip; workgroups that have work
+    uint32_t cbx_n, cby0, cby_n, n_rows; // centre blocks of the strip; rows of them over all frames
     uint32_t max_steps, pos_bits;
     uint8_t prec[3];
     uint8_t *raw; // (d as u8) per pixel of the strip, depth_image.rs:121
     uint32_t raw_stride;
     uint32_t *max_word; // per frame, depth_image.rs:124
     unsigned long long *stats;
-    // ring_quad_kernel: pixels whose colour is far from their centre's other pixels go to
-    // ring_list_kernel instead -- frame f's at defer_q / defer_ids + f * defer_stride
-    // Every frame has kDeferParts queues (workgroup % kDeferParts picks one), so that the
-    // appends do not all hit one address: queue u = f * kDeferParts + part lives at
-    // defer_q / defer_ids + u * defer_stride, its length at defer_count[u * kDeferPad].
-    Query *defer_q;
-    uint32_t *defer_ids;   // where the result goes: (y - row0) * w + x
-    uint32_t *defer_count; // zeroed
-    uint32_t defer_stride;
 };
-constexpr uint32_t kDeferParts = 64; // queues per frame
-constexpr uint32_t kDeferPad = 32;   // words between two queues' counters (own 128-byte lines)
 
 __device__ __forceinline__ uint32_t rfl(uint32_t v)
 {
@@ -133,10 +122,6 @@ __device__ __forceinline__ uint32_t wave_max_dpp(uint32_t v)
 // <= 80 SGPRs keep 8 workgroups of 256 threads resident per CU (MI355X_MICROARCH.md,
 // "Residency": 800 / (sgprs + 16)); the kernel wants 106, the spills to vector lanes cost less
 // than the eighth wave per SIMD brings (1.28 -> 1.22 ms; 96: 1.23, 64: 1.24)
-#ifndef STEPTH_NEAR_R
-#define STEPTH_NEAR_R 3
-#endif
-constexpr int kNearR = STEPTH_NEAR_R;
 template <bool STATS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void ring_tile_kernel(TileArgs a)
 {
@@ -145,15 +130,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void ring
     [[maybe_unused]] const unsigned long long pc_t0 = STEPTH_TICK();
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wv = rfl(threadIdx.x >> 6);
-    // Workgroup ids go round-robin over the 8 XCDs; give every XCD one contiguous range of
-    // centre blocks (one frame of a batch of 8, or a band of rows), so that neighbouring
-    // workgroups -- which read the same cells -- share an L2.
-    const uint32_t L = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-    if (L >= a.n_wg)
+    // Workgroup ids go round-robin over the 8 XCDs.  Rows of centre blocks (the frames of a batch
+    // stacked) are dealt to the XCDs in turn: every XCD gets an eighth of every frame and of
+    // every part of it -- frames and image regions differ a lot in work, and an XCD that owned
+    // one frame (or one band of a single frame) finished well before or after the others
+    // (1.16 -> 1.02 ms on the bench frames).  The workgroups an XCD runs at one time are still
+    // neighbours in a row and read the same cells through its L2.
+    const uint32_t xcd = blockIdx.x & 7u, xi = blockIdx.x >> 3;
+    const uint32_t g = xcd + 8u * (xi / a.cbx_n); // row of centre blocks, all frames stacked
+    if (g >= a.n_rows)
         return;
-    const uint32_t per_frame = a.cbx_n * a.cby_n;
-    const uint32_t f = L / per_frame, rr = L - f * per_frame;
-    const int CBY = (int)(a.cby0 + rr / a.cbx_n), CBX = (int)(rr % a.cbx_n);
+    const uint32_t f = g / a.cby_n;
+    const int CBY = (int)(a.cby0 + g % a.cby_n), CBX = (int)(xi % a.cbx_n);
     const uint32_t tf = f * a.t_stride;
     const uint2 *BBf = a.BBp + (size_t)f * a.bb_stride;
     const uint2 *SBf = a.SBp + (size_t)f * a.sb_stride;
@@ -210,11 +198,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void ring
             bool want;
             if (it == 0) {
                 // step 0: block-rings 0..3 around the centre block
-                bx0 = CBX - kNearR;
-                by0 = CBY - kNearR;
-                allow = kNearR == 3 ? 0x007F7F7F7F7F7F7Full : 0x0000001F1F1F1F1Full;
+                bx0 = CBX - 3;
+                by0 = CBY - 3;
+                allow = 0x007F7F7F7F7F7F7Full; // 7 rows x 7 columns
                 r_lo = 0;
-                r_hi = kNearR;
+                r_hi = 3;
                 want = q.limit != 0u;
                 if constexpr (STATS)
                     ++n_near;
@@ -225,7 +213,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void ring
                 if (it == 1) {
                     // settled: best ring <= 24, or nothing beyond ring 24 to search
                     if (q.limit != 0u &&
-                        (s_end <= 8u * kNearR + 1u || (q.best != kTileNoKey && (q.best >> ring_shift) <= 8u * kNearR)))
+                        (s_end <= 25u || (q.best != kTileNoKey && (q.best >> ring_shift) <= 24u)))
                         q.limit = 0u;
                     if (!__builtin_amdgcn_ballot_w64(q.limit != 0u))
                         break;
@@ -288,9 +276,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void ring
                     continue;
                 bx0 = sx * 8;
                 by0 = sy * 8;
-                allow = ~window_le_mask(bx0, by0, CBX, CBY, kNearR); // step 0 did block-rings 0..3
+                allow = ~window_le_mask(bx0, by0, CBX, CBY, 3); // step 0 did block-rings 0..3
                 window_ring_range(bx0, by0, CBX, CBY, r_lo, r_hi);
-                r_lo = max(r_lo, kNearR + 1);
+                r_lo = max(r_lo, 4);
                 if constexpr (STATS)
                     ++n_super;
             }
@@ -308,7 +296,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void ring
                 const uint2 *win = BBf + (size_t)(by0 + kPadB) * a.bwp + (size_t)(bx0 + kPadB);
                 auto do_row = [&](uint32_t acc, int row) __attribute__((always_inline)) -> uint32_t {
                     const int ry0 = (by0 + row) * 8 - (wy0 + 3), ry1 = wy0 - ((by0 + row) * 8 + 7);
-                    if (max(max(ry0, ry1), 0) >= (int)wlim || (it == 0 && row > 2 * kNearR))
+                    if (max(max(ry0, ry1), 0) >= (int)wlim || (it == 0 && row == 7))
                         return acc << 8;
                     const uint4 *rp4 = reinterpret_cast<const uint4 *>(win + (size_t)row * a.bwp);
                     if (need_h) {
@@ -441,387 +429,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void ring
 }
 
 // ---------------------------------------------------------------------------------------
-// "lane = centre" variant of ring_tile_kernel: one lane owns the <= 4 pixels that share a search
-// centre (tile_lane.h, LaneC), a wave one 8x8 block of centres = 16x16 pixels, a workgroup 2x2
-// such blocks.  The wave-level walk is the one above -- step 0, survey, nearest superblock first
-// -- but every bound test, survey entry and line read now serves four pixels: neighbouring
-// pixels have neighbouring colour boxes and used to repeat each other's work lane by lane.
-// ---------------------------------------------------------------------------------------
-template <bool STATS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void ring_quad_kernel(TileArgs a)
-{
-    [[maybe_unused]] ProbeCounters pcnt{};
-    [[maybe_unused]] unsigned long long pc_tests = 0, pc_survey = 0, pc_probe = 0, pc_setup = 0;
-    [[maybe_unused]] const unsigned long long pc_t0 = STEPTH_TICK();
-    [[maybe_unused]] unsigned long long pc_iters = 0;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wv = rfl(threadIdx.x >> 6);
-    const uint32_t L = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3); // XCD-contiguous
-    if (L >= a.n_wg)
-        return;
-    const uint32_t gx_n = (a.cbx_n + 1u) >> 1, gy_n = (a.cby_n + 1u) >> 1;
-    const uint32_t per_frame = gx_n * gy_n;
-    const uint32_t f = L / per_frame, rr = L - f * per_frame;
-    const uint32_t cbyi = 2u * (rr / gx_n) + (wv >> 1), cbxi = 2u * (rr % gx_n) + (wv & 1u);
-    if (cbxi >= a.cbx_n || cbyi >= a.cby_n)
-        return; // (no barriers in this kernel)
-    const int CBY = (int)(a.cby0 + cbyi), CBX = (int)cbxi;
-    const uint32_t tf = f * a.t_stride;
-    const uint2 *BBf = a.BBp + (size_t)f * a.bb_stride;
-    const uint2 *SBf = a.SBp + (size_t)f * a.sb_stride;
-    const uint32_t pb = a.pos_bits, ring_shift = pb + 2u;
-
-    // ---- the lane's centre and its four pixels ----
-    const uint32_t cx = (uint32_t)CBX * 8u + (lane & 7u), cy = (uint32_t)CBY * 8u + (lane >> 3);
-    LaneC q;
-    q.qx = (int)cx;
-    q.qy = (int)cy;
-    q.ulo = q.uhi = 0u;
-    q.hmask = 0u;
-    q.ulimit = 0u;
-    uint32_t s_end = 0;
-    bool valid[4];
-    unsigned long long n_ring0 = 0, n_tests = 0, n_probed = 0, n_near = 0, n_survey = 0, n_super = 0;
-    {
-        const bool centre_in = cx < a.wa && cy < a.ha && a.max_steps > 0;
-        uint32_t cell = kNoCell;
-        if (centre_in) {
-            cell = a.T[tf + ((uint32_t)CBY * a.bw + (uint32_t)CBX) * 64u + ((cy & 7u) << 3) + (cx & 7u)];
-            const uint32_t smax = max(max(cx, a.wa - 1u - cx), max(cy, a.ha - 1u - cy));
-            s_end = min(a.max_steps, smax + 1u); // rings 0..s_end-1 hold in-bounds cells
-        }
-        uint32_t near_lo[4], near_hi[4], pv[4]; // colours within a quarter of the precision
-        const uint8_t tol[3] = {(uint8_t)(a.prec[0] / 4u + 1u), (uint8_t)(a.prec[1] / 4u + 1u),
-                                (uint8_t)(a.prec[2] / 4u + 1u)};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint32_t x = 2u * cx - 1u + (uint32_t)(j & 1), y = 2u * cy - 1u + (uint32_t)(j >> 1);
-            valid[j] = x < a.w && y >= a.row0 && y < a.row1 && a.rp.owns(y); // (wrapped = invalid)
-#ifdef STEPTH_QUAD_ONLY0
-            valid[j] = valid[j] && j == 0;
-#endif
-            q.lo[j] = q.hi[j] = 0u;
-            near_lo[j] = near_hi[j] = pv[j] = 0u;
-            q.best[j] = kTileNoKey;
-            q.limit[j] = 0u;
-            if (valid[j]) {
-                const uint8_t *p = a.main_px[f] + (size_t)y * a.mstride + (size_t)x * a.mch;
-                const uint8_t v[3] = {p[0], p[1], p[2]};
-                make_box(v, a.prec, q.lo[j], q.hi[j]);
-                make_box(v, tol, near_lo[j], near_hi[j]);
-                pv[j] = pack_cell(v[0], v[1], v[2]);
-                if (centre_in) {
-                    if (cell_in_box(cell, q.lo[j], q.hi[j]))
-                        q.best[j] = 0u; // ring 0, distance 0 (helpers.rs:26-35 with s = 0)
-                    else if (s_end > 1u)
-                        q.limit[j] = s_end;
-                    if constexpr (STATS)
-                        n_ring0 += q.best[j] == 0u;
-                }
-            }
-        }
-        // The lane searches for the largest set of its pixels whose colours lie within a quarter
-        // of the precision of one of them (the hull of their boxes is then at most 1.25 boxes
-        // wide); the others -- pixels on a colour edge -- are handed to ring_list_kernel, which
-        // gives every query a lane of its own.
-        if (a.defer_q) {
-            uint32_t score[4], close[4]; // close[j] bit k: searching member k is near member j
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                close[j] = 0u;
-#pragma unroll
-                for (int k2 = 0; k2 < 4; ++k2)
-                    close[j] |= q.limit[k2] != 0u && cell_in_box(pv[k2], near_lo[j], near_hi[j]) ? 1u << k2 : 0u;
-                score[j] = q.limit[j] != 0u ? (uint32_t)__builtin_popcount(close[j]) : 0u;
-            }
-            uint32_t keep = close[0], top = score[0];
-#pragma unroll
-            for (int j = 1; j < 4; ++j) {
-                keep = score[j] > top ? close[j] : keep;
-                top = score[j] > top ? score[j] : top;
-            }
-            uint32_t defer = 0u;
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                defer |= q.limit[j] != 0u && ((keep >> j) & 1u) == 0u ? 1u << j : 0u;
-            const uint32_t n_mine = (uint32_t)__builtin_popcount(defer);
-            if (__builtin_amdgcn_ballot_w64(n_mine != 0u)) {
-                // wave-wide exclusive prefix of n_mine and one atomic for the wave
-                uint32_t incl = n_mine;
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    const uint32_t up = (uint32_t)__shfl_up((int)incl, o, 64);
-                    incl += lane >= (uint32_t)o ? up : 0u;
-                }
-                const uint32_t total = bcast(incl, 63);
-                uint32_t base = 0u;
-                const uint32_t u = f * kDeferParts + rr % kDeferParts;
-                if (lane == 0)
-                    base = atomicAdd(a.defer_count + u * kDeferPad, total);
-                base = bcast(base, 0);
-                uint32_t slot = base + incl - n_mine;
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if ((defer >> j) & 1u) {
-                        const uint32_t x = 2u * cx - 1u + (uint32_t)(j & 1), y = 2u * cy - 1u + (uint32_t)(j >> 1);
-                        const size_t o = (size_t)u * a.defer_stride + slot++;
-                        a.defer_q[o] = Query{cx, cy, q.lo[j], q.hi[j]};
-                        a.defer_ids[o] = (y - a.row0) * a.w + x;
-                        q.limit[j] = 0u;
-                        valid[j] = false; // ring_list_kernel writes this pixel
-                    }
-            }
-        }
-        lane_update_limit(q);
-    }
-
-    pc_setup = STEPTH_TICK() - pc_t0;
-    if (__builtin_amdgcn_ballot_w64(q.ulimit != 0u)) {
-        lane_hull(q, 0u);
-        const int R = (int)a.max_steps - 1;
-        const int wx0 = CBX * 8, wy0 = CBY * 8;
-        const int sx0 = max(wx0 - R, 0) >> 6, sy0 = max(wy0 - R, 0) >> 6;
-        const int sx1 = min(wx0 + 7 + R, (int)a.wa - 1) >> 6, sy1 = min(wy0 + 7 + R, (int)a.ha - 1) >> 6;
-        const int nsx = sx1 - sx0 + 1, nsy = sy1 - sy0 + 1; // <= 10 each for max_steps <= 263
-        uint32_t skey0 = kTileNoKey, skey1 = kTileNoKey, skey2 = kTileNoKey; // slot ty*16+tx
-
-        for (uint32_t it = 0;; ++it) {
-            int bx0, by0, r_lo, r_hi;
-            uint64_t allow;
-            bool want;
-            uint32_t d_step = 0; // no cell of the step's window is nearer than this ring
-            if (it == 0) {
-                bx0 = CBX - 3; // step 0: block-rings 0..3 around the centre block
-                by0 = CBY - 3;
-                allow = 0x007F7F7F7F7F7F7Full;
-                r_lo = 0;
-                r_hi = 3;
-                want = q.ulimit != 0u;
-                if constexpr (STATS)
-                    ++n_near;
-            } else {
-                if (it == 1) {
-                    // settled: best ring <= 24, or nothing beyond ring 24 to search
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (q.limit[j] != 0u &&
-                            (s_end <= 25u || (q.best[j] != kTileNoKey && (q.best[j] >> ring_shift) <= 24u)))
-                            q.limit[j] = 0u;
-                    lane_update_limit(q);
-                    if (!__builtin_amdgcn_ballot_w64(q.ulimit != 0u))
-                        break;
-                    lane_hull(q, 25u); // everything from here on lies at rings >= 25
-                    if constexpr (STATS)
-                        ++n_survey;
-                    [[maybe_unused]] const unsigned long long pc_s0 = STEPTH_TICK();
-                    for (int ty = 0; ty < nsy; ++ty) {
-                        const int sy = sy0 + ty;
-                        const uint4 *sb4 = reinterpret_cast<const uint4 *>(SBf + (size_t)sy * a.sbwp + sx0);
-                        const uint4 g0 = sb4[0], g1 = sb4[1], g2 = sb4[2], g3 = sb4[3], g4 = sb4[4];
-                        const int ay = (sy << 6) - q.qy;
-                        const int dsy = max(max(ay, -63 - ay), 0);
-                        const uint32_t sbv[20] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w, g2.x, g2.y,
-                                                  g2.z, g2.w, g3.x, g3.y, g3.z, g3.w, g4.x, g4.y, g4.z, g4.w};
-#pragma unroll
-                        for (int tx = 0; tx < 10; ++tx) {
-                            if (tx >= nsx)
-                                break;
-                            const int ax = ((sx0 + tx) << 6) - q.qx;
-                            const uint32_t dS = (uint32_t)max(max(max(ax, -63 - ax), 0), dsy);
-                            const bool w = dS < q.ulimit && box_meets(sbv[2 * tx], sbv[2 * tx + 1], q.ulo, q.uhi);
-                            if constexpr (STATS)
-                                n_tests += q.ulimit != 0u;
-                            if (__builtin_amdgcn_ballot_w64(w)) {
-                                // distance from the middle of the wave's centres orders the visits
-                                const int rx = ((sx0 + tx) << 6) - (wx0 + 4), ry = (sy << 6) - (wy0 + 4);
-                                const uint32_t dref = (uint32_t)max(max(max(rx, -63 - rx), max(ry, -63 - ry)), 0);
-                                const uint32_t t = (uint32_t)(ty * 16 + tx);
-                                const uint32_t key = (dref << 8) | t;
-                                if (lane == (t & 63u)) {
-                                    if (t < 64u)
-                                        skey0 = key;
-                                    else if (t < 128u)
-                                        skey1 = key;
-                                    else
-                                        skey2 = key;
-                                }
-                            }
-                        }
-                    }
-                    pc_survey += STEPTH_TICK() - pc_s0;
-                }
-                // slots come by distance from the point (wx0+4, wy0+4), which is within 4 rings of
-                // every lane's own distance: past the largest limit + 4 nothing is left
-                const uint32_t pick = wave_min_dpp(min(min(skey0, skey1), skey2));
-                if (pick == kTileNoKey || (pick >> 8) >= wave_max_dpp(q.ulimit) + 4u)
-                    break;
-                skey0 = skey0 == pick ? kTileNoKey : skey0;
-                skey1 = skey1 == pick ? kTileNoKey : skey1;
-                skey2 = skey2 == pick ? kTileNoKey : skey2;
-                const int sx = sx0 + (int)(pick & 15u), sy = sy0 + (int)((pick >> 4) & 15u);
-                const uint2 sb = SBf[(size_t)sy * a.sbwp + sx];
-                const int ax = (sx << 6) - q.qx, ay = (sy << 6) - q.qy;
-                const uint32_t dS = (uint32_t)max(max(max(ax, -63 - ax), max(ay, -63 - ay)), 0);
-                d_step = max(dS, 25u);
-                lane_hull(q, d_step); // members that still want cells this far out
-                want = dS < q.ulimit && box_meets(sb.x, sb.y, q.ulo, q.uhi);
-                if (!__builtin_amdgcn_ballot_w64(want))
-                    continue;
-                bx0 = sx * 8;
-                by0 = sy * 8;
-                allow = ~window_le_mask(bx0, by0, CBX, CBY, 3); // step 0 did block-rings 0..3
-                window_ring_range(bx0, by0, CBX, CBY, r_lo, r_hi);
-                r_lo = max(r_lo, 4);
-                if constexpr (STATS)
-                    ++n_super;
-            }
-
-            // ---- bounds of the window's 8x8 blocks against the lane's union box ----
-            uint32_t m_lo = 0, m_hi = 0; // bit row*8+col
-            [[maybe_unused]] const unsigned long long pc_b0 = STEPTH_TICK();
-            const uint32_t wlim = wave_max_dpp(want ? q.ulimit : 0u);
-            {
-                const int cx_l = bx0 * 8 - (wx0 + 7), cx_r = wx0 - (bx0 * 8 + 31); // cols 0..3
-                const bool need_l = max(max(cx_l, cx_r), 0) < (int)wlim;
-                const bool need_h = max(max(cx_l + 32, cx_r - 32), 0) < (int)wlim;   // cols 4..7
-                const uint2 *win = BBf + (size_t)(by0 + kPadB) * a.bwp + (size_t)(bx0 + kPadB);
-                auto do_row = [&](uint32_t acc, int row) __attribute__((always_inline)) -> uint32_t {
-                    const int ry0 = (by0 + row) * 8 - (wy0 + 7), ry1 = wy0 - ((by0 + row) * 8 + 7);
-                    if (max(max(ry0, ry1), 0) >= (int)wlim || (it == 0 && row == 7))
-                        return acc << 8;
-                    const uint4 *rp4 = reinterpret_cast<const uint4 *>(win + (size_t)row * a.bwp);
-                    if (need_h) {
-                        const uint4 v2 = rp4[2], v3 = rp4[3];
-                        acc = test_half_row(acc, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w, q.ulo, q.uhi);
-                    } else {
-                        acc <<= 4;
-                    }
-                    if (need_l) {
-                        const uint4 v0 = rp4[0], v1 = rp4[1];
-                        acc = test_half_row(acc, v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, q.ulo, q.uhi);
-                    } else {
-                        acc <<= 4;
-                    }
-                    return acc;
-                };
-#pragma unroll
-                for (int row = 7; row >= 4; --row)
-                    m_hi = do_row(m_hi, row);
-#pragma unroll
-                for (int row = 3; row >= 0; --row)
-                    m_lo = do_row(m_lo, row);
-            }
-            if constexpr (STATS)
-                n_tests += want ? 64u : 0u;
-            uint64_t cand = want ? (((uint64_t)m_hi << 32) | m_lo) & allow : 0ull;
-            [[maybe_unused]] const unsigned long long pc_p0 = STEPTH_TICK();
-            pc_tests += pc_p0 - pc_b0;
-
-            // ---- probe the passing blocks, block-ring by block-ring (nearest first) ----
-            uint64_t le_prev = r_lo > 0 ? window_le_mask(bx0, by0, CBX, CBY, r_lo - 1) : 0ull;
-            for (int r = r_lo; r <= r_hi; ++r) {
-                const uint64_t le = window_le_mask(bx0, by0, CBX, CBY, r);
-                uint64_t cur = cand & le & ~le_prev;
-                le_prev = le;
-                // a block of block-ring r has no cell nearer than ring 8(r-1)+1
-                if (8 * (r - 1) + 1 >= (int)wlim)
-                    break;
-                if (8 * (r - 1) + 1 >= (int)q.ulimit)
-                    cand = 0ull; // this lane is through with the window
-                if (!__builtin_amdgcn_ballot_w64((cand & ~(le & ~cur)) != 0ull))
-                    break; // no lane has a candidate in this or a later block-ring
-                if (8 * (r - 1) + 1 >= (int)q.ulimit)
-                    cur = 0ull;
-                if (!__builtin_amdgcn_ballot_w64(cur != 0ull))
-                    continue;
-                lane_hull(q, max(d_step, (uint32_t)max(8 * (r - 1) + 1, 0)));
-                while (cur != 0ull) {
-                    STEPTH_CNT(&pcnt, 0);
-#ifdef STEPTH_TILE_PROFILE
-                    if (__builtin_amdgcn_ballot_w64(true) && lane == (uint32_t)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true)))
-                        ++pc_iters;
-#endif
-                    const int k = __builtin_ctzll(cur);
-                    cur &= cur - 1ull;
-                    const int bx = bx0 + (k & 7), by = by0 + (k >> 3);
-                    const int x0 = bx * 8 - q.qx, y0 = by * 8 - q.qy;
-                    // the dmin test also keeps stale bounds of rows this call did not pack
-                    // (they are out of every query's reach) from ever being probed
-                    if ((uint32_t)square_dmin(x0, y0, 8) < q.ulimit) {
-                        const uint32_t boff = tf + ((uint32_t)by * a.bw + (uint32_t)bx) * 64u;
-                        const uint32_t nl =
-                            probe_block_c(q, x0, y0, pb, a.T + boff, a.TT + boff,
-                                          reinterpret_cast<const uint32_t *>(a.LB) + (boff >> 1), &pcnt);
-                        if constexpr (STATS) {
-                            ++n_probed;
-                            n_tests += 8u * nl;
-                        }
-                    }
-                }
-            }
-            pc_probe += STEPTH_TICK() - pc_p0;
-        }
-    }
-
-    // ---- distance, store, max (depth_image.rs:118-124) ----
-    uint32_t dmax = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        uint32_t d8 = 0;
-        if (q.best[j] != kTileNoKey && q.best[j] != 0u)
-            d8 = key_distance(q.best[j], pb) & 0xffu; // `d as u8` wraps (depth_image.rs:121)
-        if (valid[j]) {
-            const uint32_t x = 2u * cx - 1u + (uint32_t)(j & 1), y = 2u * cy - 1u + (uint32_t)(j >> 1);
-            a.raw[(size_t)f * a.raw_stride + (size_t)(y - a.row0) * a.w + x] = (uint8_t)d8;
-        }
-        dmax = max(dmax, d8);
-    }
-    const uint32_t wmax = wave_max_dpp(dmax);
-    if (lane == 0 && wmax > __hip_atomic_load(a.max_word + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-        atomicMax(a.max_word + f, wmax);
-    if constexpr (STATS) {
-        unsigned long long v0 = n_ring0, v1 = n_tests, v5 = n_probed;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            v0 += __shfl_xor(v0, o, 64);
-            v1 += __shfl_xor(v1, o, 64);
-            v5 += __shfl_xor(v5, o, 64);
-        }
-        if (lane == 0) {
-            atomicAdd(&a.stats[0], v0);
-            atomicAdd(&a.stats[1], v1);
-#ifdef STEPTH_TILE_PROFILE
-            const unsigned long long pc_all = STEPTH_TICK() - pc_t0;
-            atomicAdd(&a.stats[2], pc_tests);
-            atomicAdd(&a.stats[3], pc_survey);
-            atomicAdd(&a.stats[4], pc_probe);
-            atomicAdd(&a.stats[5], pc_all);
-            atomicAdd(&a.stats[8], pc_setup);
-            atomicMax(&a.stats[9], pc_all);
-        }
-        {
-            unsigned long long it = pc_iters; // one lane counted each iteration: sum over the wave
-            for (int o = 32; o > 0; o >>= 1)
-                it += __shfl_xor(it, o, 64);
-            if (lane == 0) {
-                atomicAdd(&a.stats[10], it);
-                atomicMax(&a.stats[11], it);
-                atomicMax(&a.stats[12], n_super);
-                atomicAdd(&a.stats[14 + min(63 - __builtin_clzll(it | 1ull), 17)], 1ull); // log2 histogram
-            }
-        }
-        if (lane == 0) {
-#else
-            atomicAdd(&a.stats[2], n_near);
-            atomicAdd(&a.stats[3], n_survey);
-            atomicAdd(&a.stats[4], n_super);
-            atomicAdd(&a.stats[5], v5);
-#endif
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------
 // PASS 1 for PREPARED QUERIES (explicit group lists, uniform tiles larger than one pixel,
 // stepth_distance_dot_array_batch): src/depth_image.rs:112-123 for arbitrary `middle`s.
 //
@@ -842,10 +449,6 @@ struct ListArgs {
     const uint32_t *ids;  // optional: results of query k go to slot ids[k] (queries sorted by bin)
     uint32_t q_stride;
     uint32_t nq[kMaxBatch];
-    // optional: ring_quad_kernel's hand-overs.  blockIdx.y = queue u, frame u / parts; the counts
-    // live on the device, queue u's at nq_dev[u * kDeferPad]
-    const uint32_t *nq_dev;
-    uint32_t parts;
     uint32_t lanes; // queries per wave: 64, or fewer for small launches
     uint32_t max_steps, pos_bits;
     uint8_t *raw; // (d as u8) per query, depth_image.rs:121
@@ -883,23 +486,19 @@ constexpr uint64_t kNearLe[4] = {0x0000000008000000ull, 0x0000001C1C1C0000ull,
 template <bool STATS>
 __global__ __launch_bounds__(256) void ring_list_kernel(ListArgs a)
 {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t u = blockIdx.y, f = a.nq_dev ? u / a.parts : u; // queue, frame
+    const uint32_t lane = threadIdx.x & 63u, f = blockIdx.y;
     // a wave takes `lanes` (16, 32 or 64) consecutive queries: a small launch is bound by the
     // latency of its slowest wave, not by issue slots, and a wave of fewer queries has fewer
     // windows to sit through
     const uint32_t i = (blockIdx.x * 4u + (threadIdx.x >> 6)) * a.lanes + lane;
-    const uint32_t nq = a.nq_dev ? a.nq_dev[u * kDeferPad] : a.nq[f];
-    if (blockIdx.x * 4u * a.lanes >= nq)
-        return; // (no barriers in this kernel)
-    const bool valid = lane < a.lanes && i < nq;
+    const bool valid = lane < a.lanes && i < a.nq[f];
     const uint32_t tf = f * a.t_stride;
     const uint2 *BBf = a.BBp + (size_t)f * a.bb_stride;
     const uint2 *SBf = a.SBp + (size_t)f * a.sb_stride;
     const uint32_t pb = a.pos_bits, ring_shift = pb + 2u;
     Query qq = Query{~0u, ~0u, 0u, 0u};
     if (valid)
-        qq = a.queries[(size_t)u * a.q_stride + i];
+        qq = a.queries[(size_t)f * a.q_stride + i];
     LaneQ q;
     q.qx = (int)qq.cx;
     q.qy = (int)qq.cy;
@@ -1151,7 +750,7 @@ __global__ __launch_bounds__(256) void ring_list_kernel(ListArgs a)
         d = isqrt_floor((uint32_t)(ddx * ddx + ddy * ddy));
     }
     if (valid) {
-        const uint32_t o = a.ids ? a.ids[(size_t)u * a.q_stride + i] : i;
+        const uint32_t o = a.ids ? a.ids[(size_t)f * a.q_stride + i] : i;
         a.raw[(size_t)f * a.raw_stride + o] = (uint8_t)(d & 0xffu); // `d as u8` wraps
         if (a.raw32)
             a.raw32[o] = d;

@@ -230,223 +230,6 @@ STEPTH_HD uint32_t probe_block(LaneQ &q, int x0, int y0, uint32_t pb, const uint
     return n;
 }
 
-// ---------------------------------------------------------------------------------------
-// "lane = centre": the <= 4 queries of a 1x1-group search that share one `middle`
-// (depth_image.rs:114-117: pixels 2cx-1..2cx x 2cy-1..2cy) in ONE lane.  They scan the same
-// cells in the same order and differ only in their colour box, and neighbouring pixels have
-// neighbouring colours: whatever can be decided with the UNION of their boxes -- which blocks
-// and lines to read -- is decided once, and only a cell inside the union box is tested against
-// the members' own boxes.  Results are those of four independent LaneQ searches, bit for bit.
-// ---------------------------------------------------------------------------------------
-struct LaneC {
-    int qx, qy;         // the shared search centre
-    uint32_t ulo, uhi;  // hull of the boxes of the members in `hmask` (lane_hull)
-    uint32_t hmask;     // bit j: member j is inside the hull
-    uint32_t lo[4], hi[4];
-    uint32_t best[4];   // per member: smallest scan key so far
-    uint32_t limit[4];  // per member: rings >= limit are of no use; 0 = not searching
-    uint32_t ulimit;    // max over limit[]: 0 = the lane is done
-};
-
-STEPTH_HD uint32_t umax32(uint32_t a, uint32_t b) { return a > b ? a : b; }
-STEPTH_HD uint32_t umin32(uint32_t a, uint32_t b) { return a < b ? a : b; }
-
-STEPTH_HD void lane_update_limit(LaneC &q)
-{
-    q.ulimit = umax32(umax32(q.limit[0], q.limit[1]), umax32(q.limit[2], q.limit[3]));
-}
-
-// The hull for objects whose nearest cell lies at ring >= d: only members that still want
-// such rings (limit > d) count -- a member that has found its hit nearby must not keep the
-// others' filter wide.  Field-wise min / max of the boxes (cell_pack.h: lo fields 0..256, hi
-// fields 512..767); recomputed only when the set of members changes.
-STEPTH_HD void lane_hull(LaneC &q, uint32_t d)
-{
-    uint32_t mask = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-        mask |= q.limit[j] > d ? 1u << j : 0u;
-    if (mask == q.hmask)
-        return;
-    q.hmask = mask;
-    uint32_t ulo = 0, uhi = 0;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        uint32_t l = 1023u, h = 0u;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint32_t lj = (q.lo[j] >> (10 * c)) & 1023u, hj = (q.hi[j] >> (10 * c)) & 1023u;
-            l = (mask >> j) & 1u ? umin32(l, lj) : l;
-            h = (mask >> j) & 1u ? umax32(h, hj) : h;
-        }
-        ulo |= l << (10 * c);
-        uhi |= h << (10 * c);
-    }
-    q.ulo = ulo; // (no member: lo > hi on every channel, nothing passes)
-    q.uhi = uhi;
-}
-
-// The 8 cells of a line, kept, with their test against the hull (see LineTest).
-struct LineCells {
-    uint32_t c[8], r[8];
-    STEPTH_HD void load(const uint32_t *p, uint32_t lo, uint32_t hi)
-    {
-#if defined(__HIP_DEVICE_COMPILE__)
-        const uint4 a = *reinterpret_cast<const uint4 *>(p), b = *reinterpret_cast<const uint4 *>(p + 4);
-        c[0] = a.x, c[1] = a.y, c[2] = a.z, c[3] = a.w, c[4] = b.x, c[5] = b.y, c[6] = b.z, c[7] = b.w;
-#else
-        for (int i = 0; i < 8; ++i)
-            c[i] = p[i];
-#endif
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-            r[i] = (c[i] - lo) & (hi - c[i]) & kGuard;
-    }
-    STEPTH_HD bool any() const
-    {
-        const uint32_t m0 = umax32(umax32(r[0], r[1]), r[2]), m1 = umax32(umax32(r[3], r[4]), r[5]);
-        return umax32(umax32(umax32(r[6], r[7]), m0), m1) == kGuard;
-    }
-    STEPTH_HD uint32_t bits() const
-    {
-        uint32_t m = 0;
-#pragma unroll
-        for (int p = 7; p >= 0; --p)
-            m = m + m + (r[p] == kGuard ? 1u : 0u);
-        return m;
-    }
-    STEPTH_HD uint32_t bits_of(uint32_t lo, uint32_t hi) const // the cells against another box
-    {
-        uint32_t m = 0;
-#pragma unroll
-        for (int p = 7; p >= 0; --p)
-            m = m + m + (cell_in_box(c[p], lo, hi) ? 1u : 0u);
-        return m;
-    }
-};
-
-// whether any lane of the wave has `b` set (host: the one "lane" there is)
-STEPTH_HD bool wave_any(bool b)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __builtin_amdgcn_ballot_w64(b) != 0ull;
-#else
-    return b;
-#endif
-}
-
-// scan_side for the members of a lane: lines are chosen with the hull and the lane's largest
-// limit.  On a line that holds cells inside the hull, those cells are tested in scan order
-// against the boxes of the members that still want the line (ring < their limit) until every
-// such member has its hit: with neighbouring pixels the first cell usually serves them all.
-template <int SIDE>
-STEPTH_HD uint32_t scan_side_c(LaneC &q, int a0, int b0, int mdb, uint32_t pb, const uint32_t *tbl,
-                               const uint32_t *lb, [[maybe_unused]] ProbeCounters *pc = nullptr)
-{
-    STEPTH_CNT(pc, 2);
-    constexpr bool neg = SIDE & 1;
-    constexpr int strict = SIDE < 2 ? 0 : 1;
-    const int s_base = neg ? -(a0 + 7) : a0;
-    const int first = imax(imax(s_base, 1), mdb + strict);
-    if (first > s_base + 7 || (uint32_t)first >= q.ulimit)
-        return 0;
-    uint32_t cand = 0;
-    STEPTH_CNT(pc, 3);
-    {
-#if defined(__HIP_DEVICE_COMPILE__)
-        const uint4 *l4 = reinterpret_cast<const uint4 *>(lb);
-        const uint4 w0 = l4[0], w1 = l4[1], w2 = l4[2], w3 = l4[3];
-        const uint32_t bx[8] = {w0.x, w0.z, w1.x, w1.z, w2.x, w2.z, w3.x, w3.z};
-        const uint32_t bn[8] = {w0.y, w0.w, w1.y, w1.w, w2.y, w2.w, w3.y, w3.w};
-        uint32_t t, u;
-        const uint32_t ng = ~kGuard;
-#define STEPTH_LT(MX, MN)                                                                      \
-    "v_sub_u32 %1, " MX ", %3\n v_sub_u32 %2, %4, " MN "\n v_and_or_b32 %1, %1, %2, %5\n"        \
-    "v_cmp_eq_u32 vcc, -1, %1\n v_addc_co_u32 %0, vcc, %0, %0, vcc\n"
-        if constexpr (neg)
-            asm(STEPTH_LT("%6", "%7") STEPTH_LT("%8", "%9") STEPTH_LT("%10", "%11") STEPTH_LT("%12", "%13")
-                    STEPTH_LT("%14", "%15") STEPTH_LT("%16", "%17") STEPTH_LT("%18", "%19") STEPTH_LT("%20", "%21")
-                : "+v"(cand), "=&v"(t), "=&v"(u)
-                : "v"(q.ulo), "v"(q.uhi), "s"(ng), "v"(bx[0]), "v"(bn[0]), "v"(bx[1]), "v"(bn[1]), "v"(bx[2]),
-                  "v"(bn[2]), "v"(bx[3]), "v"(bn[3]), "v"(bx[4]), "v"(bn[4]), "v"(bx[5]), "v"(bn[5]),
-                  "v"(bx[6]), "v"(bn[6]), "v"(bx[7]), "v"(bn[7])
-                : "vcc");
-        else
-            asm(STEPTH_LT("%20", "%21") STEPTH_LT("%18", "%19") STEPTH_LT("%16", "%17") STEPTH_LT("%14", "%15")
-                    STEPTH_LT("%12", "%13") STEPTH_LT("%10", "%11") STEPTH_LT("%8", "%9") STEPTH_LT("%6", "%7")
-                : "+v"(cand), "=&v"(t), "=&v"(u)
-                : "v"(q.ulo), "v"(q.uhi), "s"(ng), "v"(bx[0]), "v"(bn[0]), "v"(bx[1]), "v"(bn[1]), "v"(bx[2]),
-                  "v"(bn[2]), "v"(bx[3]), "v"(bn[3]), "v"(bx[4]), "v"(bn[4]), "v"(bx[5]), "v"(bn[5]),
-                  "v"(bx[6]), "v"(bn[6]), "v"(bx[7]), "v"(bn[7])
-                : "vcc");
-#undef STEPTH_LT
-#else
-        for (int i = 7; i >= 0; --i) {
-            const int l = neg ? 7 - i : i;
-            cand = cand + cand + (box_meets(lb[2 * l], lb[2 * l + 1], q.ulo, q.uhi) ? 1u : 0u);
-        }
-#endif
-    }
-    cand &= 0xFFu << (first - s_base);
-    uint32_t n_lines = 0;
-#pragma unroll 1
-    while (cand) {
-        const int i = __builtin_ctz(cand);
-        cand &= cand - 1u;
-        const int s = s_base + i;
-        if ((uint32_t)s >= q.ulimit)
-            break;
-        const int line = neg ? 7 - i : i;
-        LineCells t;
-        t.load(tbl + line * 8, q.ulo, q.uhi);
-        ++n_lines;
-        STEPTH_CNT(pc, 4);
-        if (t.any()) {
-            STEPTH_CNT(pc, 5);
-            const int r = s - strict; // cells with |b| <= r belong to this side
-            const int p0 = imax(0, -r - b0), p1 = imin(7, r - b0);
-            uint32_t live = 0; // bit j: member j wants this line and has nothing on it yet
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                live |= (uint32_t)s < q.limit[j] ? 1u << j : 0u;
-            const uint32_t kbase = ((((uint32_t)s << 2) | (uint32_t)SIDE) << pb) + (uint32_t)(b0 + s);
-            // positions in scan order; a position is visited only while some lane of the wave has
-            // a cell inside its hull there and a member still open
-#pragma unroll
-            for (int p = 0; p < 8; ++p) {
-                const bool take = live != 0u && t.r[p] == kGuard && p >= p0 && p <= p1;
-                if (!wave_any(take))
-                    continue;
-                STEPTH_CNT(pc, 6);
-                if (take) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const bool hit = ((live >> j) & 1u) != 0u && cell_in_box(t.c[p], q.lo[j], q.hi[j]);
-                        q.best[j] = hit ? umin32(q.best[j], kbase + (uint32_t)p) : q.best[j];
-                        q.limit[j] = hit ? umin32(q.limit[j], (uint32_t)s + 1u) : q.limit[j];
-                        live = hit ? live & ~(1u << j) : live;
-                    }
-                }
-            }
-            lane_update_limit(q);
-        }
-    }
-    return n_lines;
-}
-
-STEPTH_HD uint32_t probe_block_c(LaneC &q, int x0, int y0, uint32_t pb, const uint32_t *rows,
-                                 const uint32_t *cols, const uint32_t *lb,
-                                 [[maybe_unused]] ProbeCounters *pc = nullptr)
-{
-    STEPTH_CNT(pc, 1);
-    const int mdx = imax(imax(x0, -(x0 + 7)), 0), mdy = imax(imax(y0, -(y0 + 7)), 0);
-    uint32_t n = scan_side_c<0>(q, y0, x0, mdx, pb, rows, lb, pc);
-    n += scan_side_c<1>(q, y0, x0, mdx, pb, rows, lb, pc);
-    n += scan_side_c<2>(q, x0, y0, mdy, pb, cols, lb + 16, pc);
-    n += scan_side_c<3>(q, x0, y0, mdy, pb, cols, lb + 16, pc);
-    return n;
-}
-
 // Blocks of an 8x8-block window (block (0,0) of the window = block (bx0, by0) of the image)
 // that lie in block-rings <= r around the centre block (cbx, cby): bit row*8+col.
 STEPTH_HD uint64_t window_le_mask(int bx0, int by0, int cbx, int cby, int r)
