@@ -4,22 +4,26 @@
 // (/root/reference/src/helpers.rs:35): per-channel |v-what| strictly below precision on all
 // three channels, i.e. v_c in [what_c-p_c+1, what_c+p_c-1] -- membership in a 3-D box.
 //
-// A cell is stored as one dword with the three channels spread into 10-bit fields and a
-// guard bit (bit 8 of each field) pre-set:
+// A cell is stored as one dword with the three channels spread into 10-bit fields:
 //
-//      bits  0..7  R   bit  8 guard   bit  9 zero
-//      bits 10..17 G   bit 18 guard   bit 19 zero
-//      bits 20..27 B   bit 28 guard   bits 29..31 zero
+//      bits  0..7  R   bits  8..9  zero
+//      bits 10..17 G   bits 18..19 zero
+//      bits 20..27 B   bits 28..31 zero
 //
-// With the query's box packed as  lo = sum lo_c << 10c  and  hi = sum (hi_c + 512) << 10c
-// no field of (cell - lo) or (hi - cell) can borrow from its neighbour, and bit 8 of field c
-// is set exactly when cell_c >= lo_c resp. cell_c <= hi_c.  One probe is therefore
-//      v_sub, v_sub, v_and_or, v_cmp           (4 VALU ops for all three channels)
-// instead of three byte extractions, three abs-diffs and three compares.
+// The query's box [l_c, h_c] is packed as two ADDENDS,  lo = sum (256 - l_c) << 10c  and
+// hi = sum (255 - h_c) << 10c.  No field of cell + lo or cell + hi can carry into its neighbour
+// (at most 511), bit 8 of field c of cell + lo is set exactly when cell_c >= l_c, and bit 8 of
+// cell + hi exactly when cell_c > h_c.  One probe is therefore
+//      A = cell + lo,  B = cell + hi,  match  <=>  (A & ~B & guard) == guard
+// -- two adds and one three-input bit operation for all three channels.  Because both tests are
+// additions of a per-query constant, two of them fit one 64-bit add (v_lshl_add_u64 issues at
+// nearly the rate of a 32-bit add on gfx950, tools/issue_microbench.hip): two cells of a line
+// against one addend, or the {max, min} pair of a block's bounds against the {lo, hi} pair.
 //
-// The all-zero dword (guard bits clear) can never satisfy the test: it is the "no cell here"
-// value used for row padding and masked lanes, which is how the reference's `None => continue`
-// (helpers.rs:44) is expressed without a branch.
+// kNoCell -- 256 in every field, which no pixel has -- fails the "<= h" test of every box: it
+// is the "no cell here" value of row padding and masked lanes, which is how the reference's
+// `None => continue` (helpers.rs:44) is expressed without a branch.  Bounds of something empty
+// are {anything, kNoCell}.
 #pragma once
 #include <stdint.h>
 
@@ -32,15 +36,13 @@
 namespace stepth {
 
 constexpr uint32_t kGuard = (1u << 8) | (1u << 18) | (1u << 28);
-constexpr uint32_t kNoCell = 0u;
+constexpr uint32_t kNoCell = kGuard;
 
-STEPTH_HD uint32_t pack_cell(uint32_t r, uint32_t g, uint32_t b)
-{
-    return (r | (g << 10) | (b << 20)) | kGuard;
-}
+STEPTH_HD uint32_t pack_cell(uint32_t r, uint32_t g, uint32_t b) { return r | (g << 10) | (b << 20); }
 
-// Box of a query colour `v` under `precision` (helpers.rs:35).  precision 0 on a channel can
-// never be satisfied (nothing is < 0): lo = 256 makes the >= test fail for every cell.
+// Box of a query colour `v` under `precision` (helpers.rs:35), as the two addends.  precision 0
+// on a channel can never be satisfied (nothing is < 0): l = 256 makes the >= test fail for
+// every cell.
 STEPTH_HD void make_box(const uint8_t v[3], const uint8_t p[3], uint32_t &lo, uint32_t &hi)
 {
     lo = 0;
@@ -57,16 +59,21 @@ STEPTH_HD void make_box(const uint8_t v[3], const uint8_t p[3], uint32_t &lo, ui
             l = l < 0 ? 0 : l;
             h = h > 255 ? 255 : h;
         }
-        lo |= (uint32_t)l << (10 * c);
-        hi |= (uint32_t)(h + 512) << (10 * c);
+        lo |= (uint32_t)(256 - l) << (10 * c);
+        hi |= (uint32_t)(255 - h) << (10 * c);
     }
 }
 
 STEPTH_HD bool cell_in_box(uint32_t cell, uint32_t lo, uint32_t hi)
 {
-    const uint32_t t = cell - lo;
-    const uint32_t u = hi - cell;
-    return ((t & u) | ~kGuard) == 0xFFFFFFFFu;
+    return ((cell + lo) & ~(cell + hi) & kGuard) == kGuard;
+}
+
+// bounds {max, min} (cell format) of a block / superblock / line meet the box on every channel:
+// max_c >= l_c and min_c <= h_c.  Empty bounds (min = kNoCell) never do.
+STEPTH_HD bool box_meets(uint32_t bmax, uint32_t bmin, uint32_t lo, uint32_t hi)
+{
+    return ((bmax + lo) & ~(bmin + hi) & kGuard) == kGuard;
 }
 
 // floor(sqrt(n)) for the reference's `(.. as f64).sqrt() as u32` (helpers.rs:3-7); exact for

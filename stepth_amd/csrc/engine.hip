@@ -270,8 +270,8 @@ int pack_additional_tiles(stepth_engine *e, uint32_t n_frames, const uint8_t *co
     TRY(reserve(e, e->SBp, sb_frame * 8 * n_frames));
     if (e->BBp.cap != bbp_cap || e->bbp_layout[0] != bw || e->bbp_layout[1] != bh ||
         e->bbp_layout[2] < n_frames) {
-        // the border around the image's blocks must be empty bounds (all zero, never matching)
-        HIP_TRY(e, hipMemsetAsync(e->BBp.p, 0, bb_frame * 8 * n_frames, e->stream));
+        // the border around the image's blocks must be empty bounds (min = kNoCell, never matching)
+        HIP_TRY(e, hipMemsetD32Async((hipDeviceptr_t)e->BBp.p, (int)kNoCell, bb_frame * 2 * n_frames, e->stream));
         e->bbp_layout[0] = bw;
         e->bbp_layout[1] = bh;
         e->bbp_layout[2] = n_frames;

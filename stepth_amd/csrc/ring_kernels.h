@@ -707,7 +707,7 @@ __global__ __launch_bounds__(256) STEPTH_SEARCH_ATTR void ring_search_kernel(Sea
 
             // box [lo,hi] meets [bmin,bmax] on every channel
             auto meets = [&](uint2 bb, uint32_t lo, uint32_t hi) {
-                return (((bb.x - lo) & (hi - bb.y)) | ~kGuard) == 0xFFFFFFFFu;
+                return box_meets(bb.x, bb.y, lo, hi);
             };
             // some member that can still use a block at distance `d` has a box meeting `bb`
             auto wanted = [&](uint2 bb, uint32_t d) {

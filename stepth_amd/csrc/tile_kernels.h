@@ -34,7 +34,7 @@
 //            at ring >= limit are skipped -- the result is the exact first hit of the
 //            reference's scan order (tile_lane.h), bit for bit.
 //
-// Bounds are stored with a border of empty (all-zero = never matching) entries, so the block
+// Bounds are stored with a border of empty (min = kNoCell: never matching) entries, so the block
 // windows need no edge cases.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -77,27 +77,15 @@ __device__ __forceinline__ uint32_t rfl(uint32_t v)
 }
 
 // Four block-bound tests (one half of a row of 8 blocks), highest column first, shifted into
-// `acc` (bit = column): per block  t = max - lo, u = hi - min, r = (t & u) | ~guard,
-// vcc = (r == ~0), acc = acc + acc + vcc  -- five VALU instructions, the bounds straight from
-// the scalar registers the s_load left them in.  (b0x, b0y) = {max, min} of the lowest column.
-__device__ __forceinline__ uint32_t test_half_row(uint32_t acc, uint32_t b0x, uint32_t b0y,
-                                                  uint32_t b1x, uint32_t b1y, uint32_t b2x,
-                                                  uint32_t b2y, uint32_t b3x, uint32_t b3y,
-                                                  uint32_t lo, uint32_t hi)
+// `acc` (bit = column): four VALU instructions per block (tile_lane.h bound_bit), the bounds
+// straight from the scalar registers the s_load left them in.  b0 = the lowest column.
+__device__ __forceinline__ uint32_t test_half_row(uint32_t acc, uint64_t b0, uint64_t b1, uint64_t b2,
+                                                  uint64_t b3, uint64_t k)
 {
-    uint32_t t, u;
-    const uint32_t ng = ~kGuard;
-#define STEPTH_BT(MX, MN)                                                                      \
-    "v_sub_u32 %1, " MX ", %3\n v_subrev_u32 %2, " MN ", %4\n v_and_or_b32 %1, %1, %2, %5\n"    \
-    "v_cmp_eq_u32 vcc, -1, %1\n v_addc_co_u32 %0, vcc, %0, %0, vcc\n"
-    asm(STEPTH_BT("%12", "%13") STEPTH_BT("%10", "%11") STEPTH_BT("%8", "%9")
-                     STEPTH_BT("%6", "%7")
-                 : "+v"(acc), "=&v"(t), "=&v"(u)
-                 : "v"(lo), "v"(hi), "s"(ng), "s"(b0x), "s"(b0y), "s"(b1x), "s"(b1y), "s"(b2x),
-                   "s"(b2y), "s"(b3x), "s"(b3y)
-                 : "vcc");
-#undef STEPTH_BT
-    return acc;
+    acc = bound_bit(acc, b3, k);
+    acc = bound_bit(acc, b2, k);
+    acc = bound_bit(acc, b1, k);
+    return bound_bit(acc, b0, k);
 }
 
 // wave-wide unsigned max in 4 DPP steps + 4 readlanes (see wave_min_dpp)
@@ -294,20 +282,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void ring
                 const bool need_l = max(max(cx_l, cx_r), 0) < (int)wlim;
                 const bool need_h = max(max(cx_l + 32, cx_r - 32), 0) < (int)wlim;   // cols 4..7
                 const uint2 *win = BBf + (size_t)(by0 + kPadB) * a.bwp + (size_t)(bx0 + kPadB);
+                const uint64_t kq = ((uint64_t)q.hi << 32) | q.lo;
                 auto do_row = [&](uint32_t acc, int row) __attribute__((always_inline)) -> uint32_t {
                     const int ry0 = (by0 + row) * 8 - (wy0 + 3), ry1 = wy0 - ((by0 + row) * 8 + 7);
                     if (max(max(ry0, ry1), 0) >= (int)wlim || (it == 0 && row == 7))
                         return acc << 8;
-                    const uint4 *rp4 = reinterpret_cast<const uint4 *>(win + (size_t)row * a.bwp);
+                    const ulonglong4 *rp4 = reinterpret_cast<const ulonglong4 *>(win + (size_t)row * a.bwp);
                     if (need_h) {
-                        const uint4 v2 = rp4[2], v3 = rp4[3];
-                        acc = test_half_row(acc, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w, q.lo, q.hi);
+                        const ulonglong4 v1 = rp4[1];
+                        acc = test_half_row(acc, v1.x, v1.y, v1.z, v1.w, kq);
                     } else {
                         acc <<= 4;
                     }
                     if (need_l) {
-                        const uint4 v0 = rp4[0], v1 = rp4[1];
-                        acc = test_half_row(acc, v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, q.lo, q.hi);
+                        const ulonglong4 v0 = rp4[0];
+                        acc = test_half_row(acc, v0.x, v0.y, v0.z, v0.w, kq);
                     } else {
                         acc <<= 4;
                     }
@@ -460,23 +449,17 @@ struct ListArgs {
 };
 
 // eight bound tests of one row of blocks held in vector registers, highest column first
-__device__ __forceinline__ uint32_t test_row_v(uint32_t acc, const uint4 &v0, const uint4 &v1,
-                                               const uint4 &v2, const uint4 &v3, uint32_t lo, uint32_t hi)
+__device__ __forceinline__ uint32_t test_row_v(uint32_t acc, const ulonglong2 &v0, const ulonglong2 &v1,
+                                               const ulonglong2 &v2, const ulonglong2 &v3, uint64_t k)
 {
-    uint32_t t, u;
-    const uint32_t ng = ~kGuard;
-#define STEPTH_BT(MX, MN)                                                                      \
-    "v_sub_u32 %1, " MX ", %3\n v_sub_u32 %2, %4, " MN "\n v_and_or_b32 %1, %1, %2, %5\n"        \
-    "v_cmp_eq_u32 vcc, -1, %1\n v_addc_co_u32 %0, vcc, %0, %0, vcc\n"
-    asm(STEPTH_BT("%20", "%21") STEPTH_BT("%18", "%19") STEPTH_BT("%16", "%17") STEPTH_BT("%14", "%15")
-            STEPTH_BT("%12", "%13") STEPTH_BT("%10", "%11") STEPTH_BT("%8", "%9") STEPTH_BT("%6", "%7")
-        : "+v"(acc), "=&v"(t), "=&v"(u)
-        : "v"(lo), "v"(hi), "s"(ng), "v"(v0.x), "v"(v0.y), "v"(v0.z), "v"(v0.w), "v"(v1.x), "v"(v1.y),
-          "v"(v1.z), "v"(v1.w), "v"(v2.x), "v"(v2.y), "v"(v2.z), "v"(v2.w), "v"(v3.x), "v"(v3.y),
-          "v"(v3.z), "v"(v3.w)
-        : "vcc");
-#undef STEPTH_BT
-    return acc;
+    acc = bound_bit(acc, v3.y, k);
+    acc = bound_bit(acc, v3.x, k);
+    acc = bound_bit(acc, v2.y, k);
+    acc = bound_bit(acc, v2.x, k);
+    acc = bound_bit(acc, v1.y, k);
+    acc = bound_bit(acc, v1.x, k);
+    acc = bound_bit(acc, v0.y, k);
+    return bound_bit(acc, v0.x, k);
 }
 
 // blocks of the 7x7 window (origin = centre block - 3) in block-rings <= r: bit row*8+col
@@ -504,6 +487,7 @@ __global__ __launch_bounds__(256) void ring_list_kernel(ListArgs a)
     q.qy = (int)qq.cy;
     q.lo = qq.lo;
     q.hi = qq.hi;
+    const uint64_t kq = ((uint64_t)q.hi << 32) | q.lo; // the addends as a pair (tile_lane.h bound_bit)
     q.best = kTileNoKey;
     q.limit = 0u;
     uint32_t s_end = 0;
@@ -552,13 +536,13 @@ __global__ __launch_bounds__(256) void ring_list_kernel(ListArgs a)
             const uint2 *win = BBf + (size_t)(cby - 3 + kPadB) * a.bwp + (size_t)(cbx - 3 + kPadB);
 #pragma unroll
             for (int row = 6; row >= 4; --row) {
-                const uint4 *rp4 = reinterpret_cast<const uint4 *>(win + (size_t)row * a.bwp);
-                m_hi = test_row_v(m_hi, rp4[0], rp4[1], rp4[2], rp4[3], q.lo, q.hi);
+                const ulonglong2 *rp4 = reinterpret_cast<const ulonglong2 *>(win + (size_t)row * a.bwp);
+                m_hi = test_row_v(m_hi, rp4[0], rp4[1], rp4[2], rp4[3], kq);
             }
 #pragma unroll
             for (int row = 3; row >= 0; --row) {
-                const uint4 *rp4 = reinterpret_cast<const uint4 *>(win + (size_t)row * a.bwp);
-                m_lo = test_row_v(m_lo, rp4[0], rp4[1], rp4[2], rp4[3], q.lo, q.hi);
+                const ulonglong2 *rp4 = reinterpret_cast<const ulonglong2 *>(win + (size_t)row * a.bwp);
+                m_lo = test_row_v(m_lo, rp4[0], rp4[1], rp4[2], rp4[3], kq);
             }
             if constexpr (STATS)
                 n_tests += 56u;
@@ -656,16 +640,16 @@ __global__ __launch_bounds__(256) void ring_list_kernel(ListArgs a)
                     const int ry0 = (by0 + row) * 8 - wy_hi, ry1 = wy_lo - ((by0 + row) * 8 + 7);
                     if (max(max(ry0, ry1), 0) >= (int)wlim)
                         return acc << 8;
-                    const uint4 *rp4 = reinterpret_cast<const uint4 *>(win + (size_t)row * a.bwp);
+                    const ulonglong4 *rp4 = reinterpret_cast<const ulonglong4 *>(win + (size_t)row * a.bwp);
                     if (need_h) {
-                        const uint4 v2 = rp4[2], v3 = rp4[3];
-                        acc = test_half_row(acc, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w, q.lo, q.hi);
+                        const ulonglong4 v1 = rp4[1];
+                        acc = test_half_row(acc, v1.x, v1.y, v1.z, v1.w, kq);
                     } else {
                         acc <<= 4;
                     }
                     if (need_l) {
-                        const uint4 v0 = rp4[0], v1 = rp4[1];
-                        acc = test_half_row(acc, v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, q.lo, q.hi);
+                        const ulonglong4 v0 = rp4[0];
+                        acc = test_half_row(acc, v0.x, v0.y, v0.z, v0.w, kq);
                     } else {
                         acc <<= 4;
                     }
@@ -723,13 +707,13 @@ __global__ __launch_bounds__(256) void ring_list_kernel(ListArgs a)
                 const uint2 *win = BBf + (size_t)(by0 + kPadB) * a.bwp + (size_t)(bx0 + kPadB);
 #pragma unroll 1
                 for (int row = 7; row >= 4; --row) {
-                    const uint4 *rp4 = reinterpret_cast<const uint4 *>(win + (size_t)row * a.bwp);
-                    m_hi = test_row_v(m_hi, rp4[0], rp4[1], rp4[2], rp4[3], q.lo, q.hi);
+                    const ulonglong2 *rp4 = reinterpret_cast<const ulonglong2 *>(win + (size_t)row * a.bwp);
+                    m_hi = test_row_v(m_hi, rp4[0], rp4[1], rp4[2], rp4[3], kq);
                 }
 #pragma unroll 1
                 for (int row = 3; row >= 0; --row) {
-                    const uint4 *rp4 = reinterpret_cast<const uint4 *>(win + (size_t)row * a.bwp);
-                    m_lo = test_row_v(m_lo, rp4[0], rp4[1], rp4[2], rp4[3], q.lo, q.hi);
+                    const ulonglong2 *rp4 = reinterpret_cast<const ulonglong2 *>(win + (size_t)row * a.bwp);
+                    m_lo = test_row_v(m_lo, rp4[0], rp4[1], rp4[2], rp4[3], kq);
                 }
                 if constexpr (STATS)
                     n_tests += 64u;
@@ -880,8 +864,8 @@ __global__ __launch_bounds__(256) void tile_pack_kernel(TilePackArgs a)
             uint4 *dst = reinterpret_cast<uint4 *>(a.T + base + l * 8u);
             dst[0] = make_uint4(cell[0], cell[1], cell[2], cell[3]);
             dst[1] = make_uint4(cell[4], cell[5], cell[6], cell[7]);
-            // a line with no cell inside the image gets the empty bounds {0,0}: never matches
-            lb[l] = mx[0] < mn[0] ? make_uint2(0u, 0u)
+            // a line with no cell inside the image gets empty bounds: never matches
+            lb[l] = mx[0] < mn[0] ? make_uint2(0u, kNoCell)
                                   : make_uint2(pack_cell(mx[0], mx[1], mx[2]), pack_cell(mn[0], mn[1], mn[2]));
         }
         // the block's bounds: fold the 8 rows (8 consecutive lanes)
@@ -909,7 +893,7 @@ __global__ __launch_bounds__(256) void tile_pack_kernel(TilePackArgs a)
         uint4 *dst = reinterpret_cast<uint4 *>(a.TT + base + l * 8u);
         dst[0] = make_uint4(cell[0], cell[1], cell[2], cell[3]);
         dst[1] = make_uint4(cell[4], cell[5], cell[6], cell[7]);
-        lb[8u + l] = mx[0] < mn[0] ? make_uint2(0u, 0u)
+        lb[8u + l] = mx[0] < mn[0] ? make_uint2(0u, kNoCell)
                                    : make_uint2(pack_cell(mx[0], mx[1], mx[2]), pack_cell(mn[0], mn[1], mn[2]));
     }
 }
@@ -952,7 +936,7 @@ __global__ __launch_bounds__(256) void tile_super_kernel(TileSuperArgs a)
     if (lane == 0)
         a.SBp[(size_t)blockIdx.y * a.sb_stride + (size_t)sy * a.sbwp + sx] =
             some ? make_uint2(pack_cell(mx[0], mx[1], mx[2]), pack_cell(mn[0], mn[1], mn[2]))
-                 : make_uint2(0u, 0u); // nothing valid here: never matches
+                 : make_uint2(0u, kNoCell); // nothing valid here: never matches
 }
 
 } // namespace stepth

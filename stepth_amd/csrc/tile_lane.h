@@ -66,13 +66,6 @@ struct LaneQ {
 STEPTH_HD int imax(int a, int b) { return a > b ? a : b; }
 STEPTH_HD int imin(int a, int b) { return a < b ? a : b; }
 
-// bounds {max, min} (cell format) of a block / superblock meet the box on every channel.
-// The all-zero pair (padding) never does.
-STEPTH_HD bool box_meets(uint32_t bmax, uint32_t bmin, uint32_t lo, uint32_t hi)
-{
-    return ((((bmax - lo) & (hi - bmin)) | ~kGuard)) == 0xFFFFFFFFu;
-}
-
 // smallest ring of any cell of a square of `side` cells whose cell (0,0) sits at offset
 // (x0, y0) from the centre
 STEPTH_HD int square_dmin(int x0, int y0, int side)
@@ -81,23 +74,47 @@ STEPTH_HD int square_dmin(int x0, int y0, int side)
     return imax(dx, dy);
 }
 
-// The 8 cells of a line against the box.  Per cell r = (cell-lo) & (hi-cell) & guard; the cell
+// One bound test shifted into `acc`: bounds = {max, min} of a block or line as one 64-bit value
+// (max in the low half), k = the query's {lo, hi} addends likewise.  Four VALU instructions:
+// {A, B} = bounds + k (one 64-bit add, no carry between the halves: cell_pack.h), r = A & ~B &
+// guard, vcc = (r == guard), acc = acc + acc + vcc.
+STEPTH_HD uint32_t bound_bit(uint32_t acc, uint64_t bounds, uint64_t k)
+{
+    const uint64_t t = bounds + k;
+    const uint32_t r = (uint32_t)t & ~(uint32_t)(t >> 32) & kGuard;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t g = kGuard;
+    asm("v_cmp_eq_u32 vcc, %2, %1\n v_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(acc) : "v"(r), "s"(g) : "vcc");
+    return acc;
+#else
+    return acc + acc + (r == kGuard ? 1u : 0u);
+#endif
+}
+
+// The 8 cells of a line against the box.  Per cell r = (cell+lo) & ~(cell+hi) & guard; the cell
 // matches iff r == guard, and since every other subset of the three guard bits is numerically
-// smaller, "some cell of the line matches" is max(r) == guard: 3 instructions per cell plus 4
-// for the max.  Only a line that holds a match pays for the per-cell bits.
+// smaller, "some cell of the line matches" is max(r) == guard.  Two cells share each add (one
+// 64-bit add of the addend in both halves): 2 instructions per cell plus 4 for the max.  Only a
+// line that holds a match pays for the per-cell bits.
 struct LineTest {
     uint32_t r[8];
     STEPTH_HD void load(const uint32_t *c, uint32_t lo, uint32_t hi)
     {
+        const uint64_t lo2 = ((uint64_t)lo << 32) | lo, hi2 = ((uint64_t)hi << 32) | hi;
 #if defined(__HIP_DEVICE_COMPILE__)
-        const uint4 a = *reinterpret_cast<const uint4 *>(c), b = *reinterpret_cast<const uint4 *>(c + 4);
-        const uint32_t v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(c), b = *reinterpret_cast<const ulonglong2 *>(c + 4);
+        const uint64_t v[4] = {a.x, a.y, b.x, b.y};
 #else
-        const uint32_t *v = c;
+        uint64_t v[4];
+        for (int p = 0; p < 4; ++p)
+            v[p] = ((uint64_t)c[2 * p + 1] << 32) | c[2 * p];
 #endif
 #pragma unroll
-        for (int p = 0; p < 8; ++p)
-            r[p] = (v[p] - lo) & (hi - v[p]) & kGuard;
+        for (int p = 0; p < 4; ++p) {
+            const uint64_t t = v[p] + lo2, u = v[p] + hi2;
+            r[2 * p] = (uint32_t)t & ~(uint32_t)u & kGuard;
+            r[2 * p + 1] = (uint32_t)(t >> 32) & ~(uint32_t)(u >> 32) & kGuard;
+        }
     }
     STEPTH_HD static uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
     STEPTH_HD bool any() const
@@ -108,9 +125,19 @@ struct LineTest {
     STEPTH_HD uint32_t bits() const // bit p: cell p matches
     {
         uint32_t m = 0;
-#pragma unroll
+#if defined(__HIP_DEVICE_COMPILE__)
+        const uint32_t g = kGuard; // vcc = (r == guard), m = m + m + vcc: two instructions per cell
+#define STEPTH_BIT(R) "v_cmp_eq_u32 vcc, %9, " R "\n v_addc_co_u32 %0, vcc, %0, %0, vcc\n"
+        asm(STEPTH_BIT("%8") STEPTH_BIT("%7") STEPTH_BIT("%6") STEPTH_BIT("%5") STEPTH_BIT("%4")
+                STEPTH_BIT("%3") STEPTH_BIT("%2") STEPTH_BIT("%1")
+            : "+v"(m)
+            : "v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]), "v"(r[4]), "v"(r[5]), "v"(r[6]), "v"(r[7]), "s"(g)
+            : "vcc");
+#undef STEPTH_BIT
+#else
         for (int p = 7; p >= 0; --p)
             m = m + m + (r[p] == kGuard ? 1u : 0u);
+#endif
         return m;
     }
 };
@@ -137,46 +164,18 @@ STEPTH_HD uint32_t scan_side(LaneQ &q, int a0, int b0, int mdb, uint32_t pb, con
     STEPTH_CNT(pc, 3);
     {
 #if defined(__HIP_DEVICE_COMPILE__)
-        const uint4 *l4 = reinterpret_cast<const uint4 *>(lb);
-        const uint4 w0 = l4[0], w1 = l4[1], w2 = l4[2], w3 = l4[3];
-        const uint32_t bx[8] = {w0.x, w0.z, w1.x, w1.z, w2.x, w2.z, w3.x, w3.z};
-        const uint32_t bn[8] = {w0.y, w0.w, w1.y, w1.w, w2.y, w2.w, w3.y, w3.w};
-#else
-        uint32_t bx[8], bn[8];
-        for (int i = 0; i < 8; ++i) {
-            bx[i] = lb[2 * i];
-            bn[i] = lb[2 * i + 1];
-        }
-#endif
-#if defined(__HIP_DEVICE_COMPILE__)
-        // five VALU instructions per bound: t = max - lo, u = hi - min, r = (t & u) | ~guard,
-        // vcc = (r == ~0), cand = cand + cand + vcc (highest scan index first)
-        uint32_t t, u;
-        const uint32_t ng = ~kGuard;
-#define STEPTH_LT(MX, MN)                                                                      \
-    "v_sub_u32 %1, " MX ", %3\n v_sub_u32 %2, %4, " MN "\n v_and_or_b32 %1, %1, %2, %5\n"        \
-    "v_cmp_eq_u32 vcc, -1, %1\n v_addc_co_u32 %0, vcc, %0, %0, vcc\n"
-        if constexpr (neg)
-            asm(STEPTH_LT("%6", "%7") STEPTH_LT("%8", "%9") STEPTH_LT("%10", "%11") STEPTH_LT("%12", "%13")
-                    STEPTH_LT("%14", "%15") STEPTH_LT("%16", "%17") STEPTH_LT("%18", "%19") STEPTH_LT("%20", "%21")
-                : "+v"(cand), "=&v"(t), "=&v"(u)
-                : "v"(q.lo), "v"(q.hi), "s"(ng), "v"(bx[0]), "v"(bn[0]), "v"(bx[1]), "v"(bn[1]), "v"(bx[2]),
-                  "v"(bn[2]), "v"(bx[3]), "v"(bn[3]), "v"(bx[4]), "v"(bn[4]), "v"(bx[5]), "v"(bn[5]),
-                  "v"(bx[6]), "v"(bn[6]), "v"(bx[7]), "v"(bn[7])
-                : "vcc");
-        else
-            asm(STEPTH_LT("%20", "%21") STEPTH_LT("%18", "%19") STEPTH_LT("%16", "%17") STEPTH_LT("%14", "%15")
-                    STEPTH_LT("%12", "%13") STEPTH_LT("%10", "%11") STEPTH_LT("%8", "%9") STEPTH_LT("%6", "%7")
-                : "+v"(cand), "=&v"(t), "=&v"(u)
-                : "v"(q.lo), "v"(q.hi), "s"(ng), "v"(bx[0]), "v"(bn[0]), "v"(bx[1]), "v"(bn[1]), "v"(bx[2]),
-                  "v"(bn[2]), "v"(bx[3]), "v"(bn[3]), "v"(bx[4]), "v"(bn[4]), "v"(bx[5]), "v"(bn[5]),
-                  "v"(bx[6]), "v"(bn[6]), "v"(bx[7]), "v"(bn[7])
-                : "vcc");
-#undef STEPTH_LT
+        // the 8 {max, min} pairs as 64-bit values, highest scan index first (bound_bit)
+        const ulonglong2 *l2 = reinterpret_cast<const ulonglong2 *>(lb);
+        const ulonglong2 w0 = l2[0], w1 = l2[1], w2 = l2[2], w3 = l2[3];
+        const uint64_t k = ((uint64_t)q.hi << 32) | q.lo;
+        const uint64_t w[8] = {w0.x, w0.y, w1.x, w1.y, w2.x, w2.y, w3.x, w3.y};
+#pragma unroll
+        for (int i = 7; i >= 0; --i)
+            cand = bound_bit(cand, w[neg ? 7 - i : i], k);
 #else
         for (int i = 7; i >= 0; --i) { // highest scan index first: it ends in the highest bit
             const int l = neg ? 7 - i : i;
-            cand = cand + cand + (box_meets(bx[l], bn[l], q.lo, q.hi) ? 1u : 0u);
+            cand = cand + cand + (box_meets(lb[2 * l], lb[2 * l + 1], q.lo, q.hi) ? 1u : 0u);
         }
 #endif
     }

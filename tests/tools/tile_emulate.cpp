@@ -32,8 +32,8 @@ extern "C" int tile_emulate(const uint8_t *main_px, uint32_t W, uint32_t H, uint
     const uint32_t bw = (wa + 7) / 8, bh = (ha + 7) / 8, sbw = (bw + 7) / 8, sbh = (bh + 7) / 8;
     const uint32_t bwp = tile_bwp(bw), bhp = tile_bhp(bh);
     std::vector<uint32_t> T((size_t)bw * bh * 64, kNoCell), TT((size_t)bw * bh * 64, kNoCell);
-    std::vector<U2> BBp((size_t)bwp * bhp, U2{0, 0}), SB((size_t)sbw * sbh, U2{0, 0});
-    std::vector<U2> LB((size_t)bw * bh * 16, U2{0, 0}); // per block: 8 row bounds, 8 column bounds
+    std::vector<U2> BBp((size_t)bwp * bhp, U2{0, kNoCell}), SB((size_t)sbw * sbh, U2{0, kNoCell});
+    std::vector<U2> LB((size_t)bw * bh * 16, U2{0, kNoCell}); // per block: 8 row bounds, 8 column bounds
     // pack (tile_pack_kernel / tile_super_kernel)
     for (uint32_t by = 0; by < bh; ++by)
         for (uint32_t bx = 0; bx < bw; ++bx) {

@@ -39,7 +39,7 @@
     "s_and_b64 %0, %0, %4\n s_ff1_i32_b64 %2, %0\n s_or_b64 %1, %1, %4\n s_bcnt1_i32_b64 %3, %1\n" \
     "s_andn2_b64 %0, %0, %4\n s_ff1_i32_b64 %2, %1\n s_xor_b64 %1, %1, %4\n s_bcnt1_i32_b64 %3, %0\n"
 
-enum Kind { K_VALU, K_SALU, K_MIX, K_SALU64, K_CMP_READLANE, K_MIX_HALF };
+enum Kind { K_VALU, K_SALU, K_MIX, K_SALU64, K_CMP_READLANE, K_MIX_HALF, K_ADD64, K_ADD64_SGPR };
 
 template <int KIND>
 __global__ __launch_bounds__(256) void issue_kernel(uint32_t iters, uint32_t *out,
@@ -54,6 +54,9 @@ __global__ __launch_bounds__(256) void issue_kernel(uint32_t iters, uint32_t *ou
     unsigned long long m0 = 0x0f0f0f0f12345678ull + iters, m1 = ~m0;
     const unsigned long long mk = 0x5555aaaa3333ccccull;
     uint32_t r0 = 0, r1 = 0;
+    unsigned long long w0 = threadIdx.x, w1 = w0 + 1, w2 = w0 + 2, w3 = w0 + 3, w4 = w0 + 4, w5 = w0 + 5,
+                       w6 = w0 + 6, w7 = w0 + 7;
+    const unsigned long long wk = 0x0000010100000303ull + iters;
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (uint32_t i = 0; i < iters; ++i) {
         if constexpr (KIND == K_VALU) {
@@ -63,6 +66,24 @@ __global__ __launch_bounds__(256) void issue_kernel(uint32_t iters, uint32_t *ou
                              : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5),
                                "+v"(v6), "+v"(v7)
                              : "v"(va), "v"(vb));
+        } else if constexpr (KIND == K_ADD64) { // 64-bit integer add (v_lshl_add_u64), all-VGPR
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                asm volatile("v_lshl_add_u64 %0, %0, 0, %8\n v_lshl_add_u64 %1, %1, 0, %8\n"
+                             "v_lshl_add_u64 %2, %2, 0, %8\n v_lshl_add_u64 %3, %3, 0, %8\n"
+                             "v_lshl_add_u64 %4, %4, 0, %8\n v_lshl_add_u64 %5, %5, 0, %8\n"
+                             "v_lshl_add_u64 %6, %6, 0, %8\n v_lshl_add_u64 %7, %7, 0, %8\n"
+                             : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3), "+v"(w4), "+v"(w5), "+v"(w6), "+v"(w7)
+                             : "v"(wk));
+        } else if constexpr (KIND == K_ADD64_SGPR) { // the same with the first operand in an SGPR pair
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                asm volatile("v_lshl_add_u64 %0, %9, 0, %0\n v_lshl_add_u64 %1, %9, 0, %1\n"
+                             "v_lshl_add_u64 %2, %9, 0, %2\n v_lshl_add_u64 %3, %9, 0, %3\n"
+                             "v_lshl_add_u64 %4, %9, 0, %4\n v_lshl_add_u64 %5, %9, 0, %5\n"
+                             "v_lshl_add_u64 %6, %9, 0, %6\n v_lshl_add_u64 %7, %9, 0, %7\n"
+                             : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3), "+v"(w4), "+v"(w5), "+v"(w6), "+v"(w7)
+                             : "v"(wk), "s"(mk));
         } else if constexpr (KIND == K_SALU) {
 #pragma unroll
             for (int k = 0; k < 4; ++k)
@@ -119,7 +140,8 @@ __global__ __launch_bounds__(256) void issue_kernel(uint32_t iters, uint32_t *ou
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     out[blockIdx.x * 256 + threadIdx.x] = v0 ^ v1 ^ v2 ^ v3 ^ v4 ^ v5 ^ v6 ^ v7 ^ s0 ^ s1 ^ s2 ^
-                                          s3 ^ s4 ^ s5 ^ s6 ^ s7 ^ (uint32_t)m0 ^ (uint32_t)m1 ^ r0 ^ r1;
+                                          s3 ^ s4 ^ s5 ^ s6 ^ s7 ^ (uint32_t)m0 ^ (uint32_t)m1 ^ r0 ^ r1 ^
+                                          (uint32_t)((w0 ^ w1 ^ w2 ^ w3 ^ w4 ^ w5 ^ w6 ^ w7) >> 7);
     if ((threadIdx.x & 63u) == 0)
         ticks[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
 }
@@ -181,6 +203,8 @@ int main()
         if (run<K_MIX>("valu32+salu24", w, 56, 24, cus)) return 1;
         if (run<K_MIX_HALF>("valu32+salu8", w, 40, 8, cus)) return 1;
         if (run<K_CMP_READLANE>("cmp+ff1+rdlane", w, 40, 24, cus)) return 1;
+        if (run<K_ADD64>("add64", w, 32, 0, cus)) return 1;
+        if (run<K_ADD64_SGPR>("add64 sgpr", w, 32, 0, cus)) return 1;
     }
     return 0;
 }
