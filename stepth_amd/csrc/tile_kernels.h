@@ -212,19 +212,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void ring
                     for (int ty = 0; ty < nsy; ++ty) {
                         const int sy = sy0 + ty;
                         // a row of the window in one go: up to 10 superblocks = 20 dwords
-                        const uint4 *sb4 = reinterpret_cast<const uint4 *>(SBf + (size_t)sy * a.sbwp + sx0);
-                        const uint4 g0 = sb4[0], g1 = sb4[1], g2 = sb4[2], g3 = sb4[3], g4 = sb4[4];
+                        // a row of the window in one go: lane i holds dword i of its <= 10 {max, min}
+                        // pairs, the loop reads them back lane by lane (an indexed array of scalar
+                        // registers would be copied whole for every use)
+                        const uint32_t row_dw = reinterpret_cast<const uint32_t *>(SBf + (size_t)sy * a.sbwp + sx0)[lane & 31u];
                         const int ay = (sy << 6) - q.qy;
                         const int dsy = max(max(ay, -63 - ay), 0);
-                        const uint32_t sbv[20] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w, g2.x, g2.y,
-                                                  g2.z, g2.w, g3.x, g3.y, g3.z, g3.w, g4.x, g4.y, g4.z, g4.w};
-#pragma unroll
-                        for (int tx = 0; tx < 10; ++tx) {
-                            if (tx >= nsx)
-                                break;
+                        for (int tx = 0; tx < nsx; ++tx) {
+                            const uint32_t bmax = (uint32_t)__builtin_amdgcn_readlane((int)row_dw, 2 * tx);
+                            const uint32_t bmin = (uint32_t)__builtin_amdgcn_readlane((int)row_dw, 2 * tx + 1);
                             const int ax = ((sx0 + tx) << 6) - q.qx;
                             const uint32_t dS = (uint32_t)max(max(max(ax, -63 - ax), 0), dsy);
-                            const bool w = dS < q.limit && box_meets(sbv[2 * tx], sbv[2 * tx + 1], q.lo, q.hi);
+                            const bool w = dS < q.limit && box_meets(bmax, bmin, q.lo, q.hi);
                             if constexpr (STATS)
                                 n_tests += q.limit != 0u;
                             if (__builtin_amdgcn_ballot_w64(w)) {
@@ -580,19 +579,15 @@ __global__ __launch_bounds__(256) void ring_list_kernel(ListArgs a)
             uint32_t skey0 = kTileNoKey, skey1 = kTileNoKey, skey2 = kTileNoKey; // slot ty*16+tx
             for (int ty = 0; ty < nsy; ++ty) {
                 const int sy = sy0 + ty;
-                const uint4 *sb4 = reinterpret_cast<const uint4 *>(SBf + (size_t)sy * a.sbwp + sx0);
-                const uint4 g0 = sb4[0], g1 = sb4[1], g2 = sb4[2], g3 = sb4[3], g4 = sb4[4];
+                const uint32_t row_dw = reinterpret_cast<const uint32_t *>(SBf + (size_t)sy * a.sbwp + sx0)[lane & 31u];
                 const int ay = (sy << 6) - q.qy;
                 const int dsy = max(max(ay, -63 - ay), 0);
-                const uint32_t sbv[20] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w, g2.x, g2.y,
-                                          g2.z, g2.w, g3.x, g3.y, g3.z, g3.w, g4.x, g4.y, g4.z, g4.w};
-#pragma unroll
-                for (int tx = 0; tx < 10; ++tx) {
-                    if (tx >= nsx)
-                        break;
+                for (int tx = 0; tx < nsx; ++tx) { // (lane i holds dword i of the row, see ring_tile_kernel)
+                    const uint32_t bmax = (uint32_t)__builtin_amdgcn_readlane((int)row_dw, 2 * tx);
+                    const uint32_t bmin = (uint32_t)__builtin_amdgcn_readlane((int)row_dw, 2 * tx + 1);
                     const int ax = ((sx0 + tx) << 6) - q.qx;
                     const uint32_t dS = (uint32_t)max(max(max(ax, -63 - ax), 0), dsy);
-                    const bool w = dS < q.limit && box_meets(sbv[2 * tx], sbv[2 * tx + 1], q.lo, q.hi);
+                    const bool w = dS < q.limit && box_meets(bmax, bmin, q.lo, q.hi);
                     if constexpr (STATS)
                         n_tests += q.limit != 0u;
                     if (__builtin_amdgcn_ballot_w64(w)) {
