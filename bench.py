@@ -186,10 +186,15 @@ def ring_leg(eng, O, frames_np, prec, max_steps, reps, check, dev, label):
     eng.stats_enable(True)
     call()
     st = eng.stats()
+    raw = eng.stats_raw(8)
     eng.stats_enable(False)
     out["gpu_items_examined_per_pixel"] = round(st["probes"] / max(st["groups"], 1), 1)
     out["gpu_blocks_probed_per_pixel"] = round(st["blocks_probed"] / max(st["groups"], 1), 3)
     out["ring0_hit_fraction"] = round(st["ring0_hits"] / max(st["groups"], 1), 4)
+    # how sharp the filters are: block probes that did not improve the query's result, and
+    # superblock visits in which no block passed its bound test for any query of the wave
+    out["block_probes_without_gain"] = round(raw[7] / max(st["blocks_probed"], 1), 3)
+    out["superblock_steps_without_candidate"] = round(raw[6] / max(st["superblock_steps"], 1), 3)
     if check == "full":
         depth, _ = eng.depth_from_additional_batch(mains[:1], adds[:1], prec, max_steps=max_steps)
         ref = O.depth_from_additional(frames_np[0][0], frames_np[0][1], prec, max_steps, (1, 1))

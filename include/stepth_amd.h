@@ -353,8 +353,10 @@ int stepth_apply_mask(stepth_engine *engine, const stepth_image *rgba, const ste
  * the counters of that call (synchronises the stream). */
 int stepth_stats_enable(stepth_engine *engine, int enable);
 int stepth_get_stats(stepth_engine *engine, stepth_stats *out);
-/* diagnostics: the first n <= 32 raw 64-bit statistic words (the 7 above, then slots that only
- * tuning builds of the library fill) */
+/* diagnostics: the first n <= 32 raw 64-bit statistic words of the last call: [0..5] the device
+ * counters above (ring0_hits .. blocks_probed), [6] superblock visits of the dense search in
+ * which no block passed its bound test, [7] its block probes that did not improve a result,
+ * then slots that only tuning builds of the library fill */
 int stepth_get_stats_raw(stepth_engine *engine, uint64_t *out, uint32_t n);
 
 /*

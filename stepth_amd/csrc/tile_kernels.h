@@ -148,6 +148,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void ring
     q.limit = 0u;
     uint32_t s_end = 0;
     unsigned long long n_ring0 = 0, n_tests = 0, n_probed = 0, n_near = 0, n_survey = 0, n_super = 0;
+    unsigned long long n_super_empty = 0, n_probe_void = 0; // steps with no candidate block / probes without gain
     if (valid) {
         const uint8_t *p = a.main_px[f] + (size_t)y * a.mstride + (size_t)x * a.mch;
         const uint8_t v[3] = {p[0], p[1], p[2]};
@@ -311,6 +312,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void ring
             if constexpr (STATS)
                 n_tests += want ? 64u : 0u;
             uint64_t cand = want ? (((uint64_t)m_hi << 32) | m_lo) & allow : 0ull;
+            if constexpr (STATS)
+                n_super_empty += it != 0 && !__builtin_amdgcn_ballot_w64(cand != 0ull);
             [[maybe_unused]] const unsigned long long pc_p0 = STEPTH_TICK();
             pc_tests += pc_p0 - pc_b0;
 
@@ -345,12 +348,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void ring
                     if ((uint32_t)square_dmin(x0, y0, 8) < q.limit) {
 #endif
                         const uint32_t boff = tf + ((uint32_t)by * a.bw + (uint32_t)bx) * 64u;
+                        [[maybe_unused]] const uint32_t best_before = q.best;
                         const uint32_t nl =
                             probe_block(q, x0, y0, pb, a.T + boff, a.TT + boff,
                                         reinterpret_cast<const uint32_t *>(a.LB) + (boff >> 1), &pcnt);
                         if constexpr (STATS) {
                             ++n_probed;
                             n_tests += 8u * nl;
+                            n_probe_void += q.best == best_before;
                         }
                     }
                 }
@@ -373,12 +378,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void ring
         atomicMax(a.max_word + f, wmax);
     if constexpr (STATS) {
         // lane-level counts: ring-0 hits, bound tests + cells examined, blocks probed
-        unsigned long long v0 = n_ring0, v1 = n_tests, v5 = n_probed;
+        unsigned long long v0 = n_ring0, v1 = n_tests, v5 = n_probed, v7 = n_probe_void;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             v0 += __shfl_xor(v0, o, 64);
             v1 += __shfl_xor(v1, o, 64);
             v5 += __shfl_xor(v5, o, 64);
+            v7 += __shfl_xor(v7, o, 64);
         }
         if (lane == 0) {
             atomicAdd(&a.stats[0], v0);
@@ -411,6 +417,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void ring
             atomicAdd(&a.stats[3], n_survey);
             atomicAdd(&a.stats[4], n_super);
             atomicAdd(&a.stats[5], v5);
+            atomicAdd(&a.stats[6], n_super_empty); // raw slots (stepth_get_stats_raw)
+            atomicAdd(&a.stats[7], v7);
 #endif
         }
     }

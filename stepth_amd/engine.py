@@ -615,6 +615,14 @@ class Engine:
         self._check(self._lib.stepth_get_stats(self._h, C.byref(s)))
         return {k: int(getattr(s, k)) for k, _t in L.Stats._fields_}
 
+    def stats_raw(self, n: int = 32) -> list:
+        """the first n raw 64-bit statistic words (stepth_get_stats_raw): the documented seven,
+        then [6] superblock steps without a candidate block and [7] block probes without gain of
+        the dense search, then slots only tuning builds fill"""
+        raw = (C.c_uint64 * n)()
+        self._check(self._lib.stepth_get_stats_raw(self._h, raw, n))
+        return [int(v) for v in raw]
+
     def kernel_time_enable(self, on: bool = True):
         self._check(self._lib.stepth_kernel_time_enable(self._h, int(on)))
 
