@@ -47,20 +47,30 @@ class StripBalancer:
     Results do not depend on where the cuts are."""
 
     def __init__(self, height: int, world: int, align: int = 2, min_rows: int = 8,
-                 damping: float = 0.7, lag: int = 1):
+                 damping: float = 0.7, lag: int = 1, phase: int = 0):
         """`lag` = calls in flight at once (steps alternating over that many streams): the
         measurement read at call k is the one of call k - lag, so reading it never waits for
-        work that is meant to overlap with call k."""
+        work that is meant to overlap with call k.  Cut points are `align * k + phase`: the dense
+        search gives a wave the pixel rows 8k-1 .. 8k+6 (two rows per search centre, the first
+        centre row holds row 0 alone), so with align 8, phase 7 no wave straddles two ranks."""
         self.lag = max(1, lag)
         self.height, self.world, self.align = height, world, max(1, align)
-        self.min_rows, self.damping = min_rows, damping
+        self.phase = phase % self.align
+        self.min_rows, self.damping = max(min_rows, self.align), damping
         self.bounds = strip_bounds(height, world, self.align)
+        if self.phase:
+            cuts = [0] + [self._snap(a) for a, _ in strip_bounds(height, world)[1:]] + [height]
+            if all(cuts[k] + self.min_rows <= cuts[k + 1] for k in range(world)):
+                self.bounds = [(cuts[k], cuts[k + 1]) for k in range(world)]
         self.last_ms: Optional[float] = None  # this rank's most recent finished measurement
         self.timed_bounds = None   # ... and the strips it was taken with
         self._open = None          # measurement being taken
         self._timings = collections.deque()  # GPU measurements not read yet
         self._pending = collections.deque()  # (all-reduced times, their bounds, event) per call
         self._updates = 0
+
+    def _snap(self, y: float) -> int:
+        return int(round((y - self.phase) / self.align)) * self.align + self.phase
 
     # -- timing of this rank's share (GPU events on the current stream, or the wall clock) --
     def start(self, on_gpu: bool):
@@ -135,7 +145,7 @@ class StripBalancer:
             # the first correction goes all the way (equal strips are far off), later ones
             # are damped against noise
             y = old + (1.0 if self._updates == 0 else self.damping) * (y - old)
-            cuts.append(int(round(y / self.align)) * self.align)
+            cuts.append(self._snap(y))
         cuts.append(self.height)
         for k in range(1, self.world):  # keep every strip at least min_rows high
             cuts[k] = max(cuts[k], cuts[k - 1] + self.min_rows)

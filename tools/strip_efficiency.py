@@ -63,8 +63,9 @@ print("ranks | frames rotate | equal strips | balanced strips (cut points follow
 for n in args.ranks:
     for rot in sorted({1, max(1, args.rotate)}):
         res = {}
+        equal_bounds = StripBalancer(H, n, align=8, phase=7).bounds  # equal strips, wave-aligned cuts
         for mode in ("equal", "balanced", "interleave16"):
-            bal = StripBalancer(H, n, align=2)
+            bal = StripBalancer(H, n, align=8, phase=7)
             pending = []  # (times, bounds) waiting for their two-step lag
             effs = []
             for step in range(args.steps):
@@ -73,7 +74,7 @@ for n in args.ranks:
                 if mode == "balanced" and len(pending) >= 2:
                     t, b = pending.pop(0)
                     bal.update([max(1, int(x * 1e3)) for x in t], b)
-                bounds = bal.bounds if mode == "balanced" else strip_bounds(H, n)
+                bounds = bal.bounds if mode == "balanced" else equal_bounds
                 if mode == "interleave16":
                     times = [timed(frames, (0, H), (16, n, r)) for r in range(n)]
                 else:
