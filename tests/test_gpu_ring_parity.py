@@ -454,6 +454,22 @@ def test_stats_counters(engine, oracle, asset):
     assert s["probes"] > 240000
 
 
+def test_raw_stats_words_of_the_dense_search(engine, asset):
+    """stepth_get_stats_raw: words 0..5 are the documented device counters, 6 and 7 the filter
+    diagnostics bench.py prints (superblock visits without a candidate block, block probes
+    that did not improve a result)"""
+    engine.stats_enable(True)
+    try:
+        engine.depth_from_additional(asset["main"], asset["additional"], P36, max_steps=255)
+        s, raw = engine.stats(), engine.stats_raw(8)
+    finally:
+        engine.stats_enable(False)
+    assert raw[0] == s["ring0_hits"] and raw[1] == s["probes"] and raw[5] == s["blocks_probed"]
+    assert raw[4] == s["superblock_steps"] > 0
+    assert 0 <= raw[6] <= s["superblock_steps"]
+    assert 0 < raw[7] < s["blocks_probed"]
+
+
 def test_depth_image_mirror_end_to_end(engine, oracle, asset, tmp_path):
     """the README flow (Readme.md:11-16) through the host mirror"""
     from PIL import Image

@@ -394,3 +394,23 @@ def test_balancer_with_a_slow_rank_that_moves_every_step():
     for bounds in hist0:
         assert bounds[0][0] == 0 and bounds[-1][1] == 61
         assert all(bounds[k][1] == bounds[k + 1][0] and bounds[k][1] - bounds[k][0] >= 4 for k in range(world - 1))
+
+
+def test_balancer_cut_points_keep_their_phase():
+    """StripBalancer(align=8, phase=7): cut points at pixel rows 8k - 1, the row pattern of the
+    dense search's waves (stepth_amd/csrc/tile_kernels.h), initially and after every update,
+    strips never below min_rows, the same on every rank (pure function of the all-reduced times)"""
+    from stepth_amd.sharding import StripBalancer
+    rng = np.random.default_rng(7)
+    for world in (2, 3, 4, 8):
+        bals = [StripBalancer(1080, world, align=8, phase=7) for _ in range(2)]
+        for _ in range(20):
+            times = [int(t) for t in rng.integers(200, 3000, world)]
+            for b in bals:
+                b.update(times, b.bounds)
+            assert bals[0].bounds == bals[1].bounds
+            cuts = [a for a, _ in bals[0].bounds[1:]]
+            assert all(c % 8 == 7 for c in cuts), cuts
+            assert bals[0].bounds[0][0] == 0 and bals[0].bounds[-1][1] == 1080
+            assert all(b - a >= 8 for a, b in bals[0].bounds)
+            assert all(bals[0].bounds[k][1] == bals[0].bounds[k + 1][0] for k in range(world - 1))

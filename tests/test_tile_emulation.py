@@ -28,6 +28,8 @@ def emu(tmp_path_factory):
                                  C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p,
                                  C.c_void_p, C.c_void_p]
 
+    lib.cell_pack_selfcheck.restype = C.c_int
+
     def run(main, add, prec, max_steps, rows=None):
         main = np.ascontiguousarray(main)
         add = np.ascontiguousarray(add[..., :3])
@@ -42,6 +44,7 @@ def emu(tmp_path_factory):
                               C.cast(C.byref(mx), C.c_void_p), C.cast(st, C.c_void_p))
         assert rc == 0, f"tile_emulate failed with {rc}"
         return raw, mx.value, list(st)
+    run.lib = lib
     return run
 
 
@@ -99,3 +102,11 @@ def test_scan_order_ties(emu, oracle):
     main = np.repeat(np.repeat(rng.integers(0, 4, (24, 40, 3), dtype=np.uint8) * 70, 9, axis=0), 9, axis=1)[:200, :340]
     _check(emu, oracle, main, add, [36] * 3, 255)
     _check(emu, oracle, main, add, [36] * 3, 40)
+
+
+def test_cell_format_arithmetic_is_the_reference_predicate(emu):
+    """cell_pack.h: the box test as two additions (cell + lo, cell + hi, A & ~B & guard), its
+    64-bit form for {max, min} bounds, the line test and the no-cell / empty values, against
+    `|v - what| < precision` on every channel (/root/reference/src/helpers.rs:35): every value
+    pair per channel for precisions 0..255, plus 200 000 random three-channel lines"""
+    assert emu.lib.cell_pack_selfcheck() == 0

@@ -265,3 +265,73 @@ extern "C" int tile_emulate(const uint8_t *main_px, uint32_t W, uint32_t H, uint
     }
     return 0;
 }
+
+// Exhaustive check of cell_pack.h's box arithmetic against the reference predicate
+// `|v - what| < precision` on every channel (/root/reference/src/helpers.rs:35), of
+// bound_bit's 64-bit form and of the empty / no-cell values.  Returns 0, or the number of the
+// first check that failed.
+extern "C" int cell_pack_selfcheck(void)
+{
+    const uint8_t precs[] = {0, 1, 2, 3, 36, 37, 128, 254, 255};
+    // one channel at a time (the others held where they match), every value pair
+    for (int ch = 0; ch < 3; ++ch)
+        for (uint8_t p : precs)
+            for (int what = 0; what < 256; ++what) {
+                uint8_t w3[3] = {77, 77, 77}, p3[3] = {5, 5, 5};
+                w3[ch] = (uint8_t)what;
+                p3[ch] = p;
+                uint32_t lo, hi;
+                make_box(w3, p3, lo, hi);
+                for (int v = 0; v < 256; ++v) {
+                    uint32_t c3[3] = {77, 77, 77};
+                    c3[ch] = (uint32_t)v;
+                    const bool want = std::abs(v - what) < (int)p;
+                    if (cell_in_box(pack_cell(c3[0], c3[1], c3[2]), lo, hi) != want)
+                        return 1;
+                    // a single-cell block: bounds {v, v}; and a block [v, v+9] against the box
+                    const uint32_t pc = pack_cell(c3[0], c3[1], c3[2]);
+                    if (box_meets(pc, pc, lo, hi) != want)
+                        return 2;
+                    const int v1 = std::min(v + 9, 255);
+                    uint32_t m3[3] = {77, 77, 77};
+                    m3[ch] = (uint32_t)v1;
+                    bool any = false;
+                    for (int u = v; u <= v1; ++u)
+                        any |= std::abs(u - what) < (int)p;
+                    const uint32_t bmax = pack_cell(m3[0], m3[1], m3[2]);
+                    if (box_meets(bmax, pc, lo, hi) != any)
+                        return 3;
+                    const uint64_t k = ((uint64_t)hi << 32) | lo, b = ((uint64_t)pc << 32) | bmax;
+                    if ((bound_bit(2u, b, k) == 5u) != any)
+                        return 4;
+                }
+                if (cell_in_box(kNoCell, lo, hi) || box_meets(0u, kNoCell, lo, hi) ||
+                    box_meets(kNoCell, kNoCell, lo, hi))
+                    return 5; // padding must never match
+            }
+    // three channels together, pseudo-random, incl. LineTest on 8 cells
+    uint32_t s = 12345u;
+    auto rnd = [&]() { return (s = s * 1664525u + 1013904223u) >> 24; };
+    for (int it = 0; it < 200000; ++it) {
+        uint8_t w3[3] = {(uint8_t)rnd(), (uint8_t)rnd(), (uint8_t)rnd()};
+        uint8_t p3[3] = {(uint8_t)(rnd() % 80), (uint8_t)(rnd() % 80), (uint8_t)(rnd() % 80)};
+        uint32_t lo, hi, cells[8], want_bits = 0;
+        make_box(w3, p3, lo, hi);
+        for (int i = 0; i < 8; ++i) {
+            uint32_t c3[3];
+            bool in = true;
+            for (int c = 0; c < 3; ++c) {
+                c3[c] = (rnd() & 1u) ? rnd() : (uint32_t)std::min(255, std::max(0, (int)w3[c] + (int)(rnd() % 9) - 4));
+                in = in && std::abs((int)c3[c] - (int)w3[c]) < (int)p3[c];
+            }
+            cells[i] = (it % 17 == 0 && i == 3) ? kNoCell : pack_cell(c3[0], c3[1], c3[2]);
+            if (cells[i] != kNoCell && in)
+                want_bits |= 1u << i;
+        }
+        LineTest t;
+        t.load(cells, lo, hi);
+        if (t.any() != (want_bits != 0) || t.bits() != want_bits)
+            return 6;
+    }
+    return 0;
+}
