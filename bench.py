@@ -407,6 +407,7 @@ def main():
         # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE,
         # gfx950-corrected) -- only for the shape that was profiled
         traffic = None
+        issue = None
         if args.mode == "ring" and world == 1 and (W, H, args.d_max) == (1920, 1080, 128) \
                 and os.path.exists(TRAFFIC_FILE):
             prof = json.load(open(TRAFFIC_FILE))
@@ -417,6 +418,21 @@ def main():
             if per_launch and prof.get("frames_per_launch") and DOMINANT_KERNEL in prof.get("dominant_kernel", "") \
                     and prof.get("kernel_source_sha16") == kernel_source_sha16():
                 traffic = int(per_launch * frames_per_launch / prof["frames_per_launch"])
+                sq = prof.get("dominant_kernel_sq_counters_per_launch") or {}
+                if sq.get("SQ_ACTIVE_INST_VALU") and klaunches and frames_per_launch == prof["frames_per_launch"]:
+                    # what actually bounds the kernel: its VALU instructions against the SIMDs'
+                    # issue slots (SQ_ACTIVE_INST_VALU counts quad-cycles; 256 CUs x 4 SIMDs at
+                    # 2.4 GHz; counters from the committed PMC passes, time measured live)
+                    simd_quad_cycles = k_avg_ms * 1e-3 * 2.4e9 / 4 * 256 * 4
+                    issue = {"bound": "valu_issue",
+                             "valu_insts_per_launch": sq.get("SQ_INSTS_VALU"),
+                             "valu_insts_per_pixel": round(sq.get("SQ_INSTS_VALU", 0) / px_launch, 2),
+                             "salu_insts_per_launch": sq.get("SQ_INSTS_SALU"),
+                             "valu_busy_frac": round(min(sq["SQ_ACTIVE_INST_VALU"] / simd_quad_cycles, 1.0), 3),
+                             "waves_resident_per_simd": round(sq.get("SQ_WAVE_CYCLES", 0) / simd_quad_cycles, 2),
+                             "cycles_per_wave64_int_valu_inst": 3.9,
+                             "source": "profiles/r2_hbm_traffic.json (rocprofv3 --pmc SQ_*), "
+                                       "profiles/r2_issue_microbench.txt"}
         n_slots = max(1, args.streams)
         out = {
             "metric": ("Mpixels/sec depth output, 1080p stereo d_max=128" if args.mode == "ring"
@@ -454,6 +470,7 @@ def main():
                 "frames_per_launch": frames_per_launch,
                 "algorithmic_bytes_per_launch": ALGO_BYTES_PER_PIXEL * px_launch,
                 "gpu_items_examined_per_pixel": None if probes_pp is None else round(probes_pp, 1),
+                "issue": issue,
                 "note": "items = bound tests + cells the GPU search examined per pixel; the "
                         "reference's own probe count for the same frame is "
                         "cpu_baseline.reference_probes_per_pixel",

@@ -68,6 +68,11 @@ def main():
                    "corrected_bytes_per_launch": int((2 * sum(fv) / len(fv) + sum(wv) / len(wv)) * 1024)}
     dom = next(k for k in kern if DOMINANT in k)
     step = sum(v["corrected_bytes_per_launch"] for v in kern.values())
+    # SQ counters (two more passes): the dominant kernel's also go into the JSON for bench.py
+    sq = counters("prof_sq")
+    for k, v in counters("prof_sq2").items():
+        sq[k].update(v)
+    dom_sq = {c: round(sum(v) / len(v)) for c, v in sorted(sq.get(dom, {}).items())}
     json.dump({
         "_about": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, as MI355X_MICROARCH.md "
                   f"prescribes) on `{cmd}`; means over launches; one launch = one batch of 8 frames 1920x1080. "
@@ -79,15 +84,13 @@ def main():
         "kernel_source_sha16": kernel_source_sha16(), "kernel_sources": KERNEL_SOURCES,
         "dominant_kernel": dom,
         "dominant_kernel_traffic_bytes_per_launch_corrected": kern[dom]["corrected_bytes_per_launch"],
+        "dominant_kernel_sq_counters_per_launch": dom_sq,
         "headline_step_kernels": sorted(kern),
         "headline_step_traffic_bytes_corrected": step,
         "kernels": kern,
     }, open(os.path.join(dst, f"{tag}_hbm_traffic.json"), "w"), indent=1)
 
     # 3. SQ counters
-    sq = counters("prof_sq")
-    for k, v in counters("prof_sq2").items():
-        sq[k].update(v)
     with open(os.path.join(dst, f"{tag}_sq_counters.txt"), "w") as f:
         f.write(f"# rocprofv3 --pmc (SQ counters, two passes); per launch = one batch of 8 frames 1920x1080\n"
                 f"# command: {cmd}\n"
