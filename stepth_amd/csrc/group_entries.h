@@ -2,7 +2,7 @@
 // of the batched group-list flow; included by engine.hip inside its extern "C" block.
 
 // grouping of nf <= kMaxBatch device images of one shape into out[f] (device, `capacity` groups
-// each; nullptr = the engine's own buffer); the counts land in e->group_counters[4 f]
+// each; nullptr = the engine's own buffer); the counts land in e->group_counters[4 f kGroupCtrPad]
 static int adaptive_groups_device(stepth_engine *e, uint32_t nf, const uint8_t *const *d_mains, size_t ms,
                                   uint32_t ch, uint32_t W, uint32_t H, const uint8_t precision[3],
                                   uint32_t min_splits, uint32_t max_splits, GroupRec *const *out)
@@ -22,7 +22,7 @@ static int adaptive_groups_device(stepth_engine *e, uint32_t nf, const uint8_t *
         TRY(reserve(e, e->group_out, (size_t)px * sizeof(GroupRec) * nf));
     for (int k = 0; k < 3; ++k)
         TRY(reserve(e, e->group_list[k], (size_t)px * sizeof(GroupNode) * nf));
-    TRY(reserve(e, e->group_counters, 16 * kMaxBatch));
+    TRY(reserve(e, e->group_counters, 16 * kGroupCtrPad * kMaxBatch));
     AdaptiveArgs a{};
     for (uint32_t f = 0; f < nf; ++f) {
         a.px[f] = d_mains[f];
@@ -41,7 +41,7 @@ static int adaptive_groups_device(stepth_engine *e, uint32_t nf, const uint8_t *
         a.list[k] = static_cast<GroupNode *>(e->group_list[k].p);
     a.list_stride = (size_t)px;
     a.counters = static_cast<uint32_t *>(e->group_counters.p);
-    HIP_TRY(e, hipMemsetAsync(a.counters, 0, 16 * nf, e->stream));
+    HIP_TRY(e, hipMemsetAsync(a.counters, 0, 16 * kGroupCtrPad * nf, e->stream));
     const uint64_t seeds = 1ull << seed_depth;
     hipLaunchKernelGGL(adaptive_seed_kernel,
                        dim3((uint32_t)std::min<uint64_t>((seeds + 255) / 256, 4096), nf), dim3(256), 0,
@@ -134,11 +134,11 @@ int stepth_adaptive_groups_batch(stepth_engine *e, uint32_t n_frames, const step
         }
         TRY(adaptive_groups_device(e, nf, d_mains, mains[0].stride, mains[0].channels, W, H, precision,
                                    min_splits, max_splits, outs));
-        uint32_t cnt[4 * kMaxBatch];
-        HIP_TRY(e, hipMemcpyAsync(cnt, e->group_counters.p, 16 * nf, hipMemcpyDeviceToHost, e->stream));
+        std::vector<uint32_t> cnt((size_t)4 * kGroupCtrPad * nf);
+        HIP_TRY(e, hipMemcpyAsync(cnt.data(), e->group_counters.p, cnt.size() * 4, hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(e, hipStreamSynchronize(e->stream));
         for (uint32_t f = 0; f < nf; ++f)
-            n_out[f0 + f] = cnt[4 * f];
+            n_out[f0 + f] = cnt[(size_t)4 * kGroupCtrPad * f];
     }
     return STEPTH_OK;
 }

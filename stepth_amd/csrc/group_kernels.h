@@ -28,6 +28,8 @@ struct GroupNode {
     uint32_t x, y, w, h;
 };
 
+constexpr uint32_t kGroupCtrPad = 32;
+
 struct AdaptiveArgs {
     const uint8_t *px[kMaxBatch]; // main images (one per frame, blockIdx.y), `ch` bytes per pixel
     size_t stride;
@@ -37,7 +39,10 @@ struct AdaptiveArgs {
     GroupRec *groups[kMaxBatch];                 // capacity W*H each
     GroupNode *list[3];                          // node lists of levels d, d+1, d+2 (rotating) ...
     size_t list_stride;                          // ... frame f's at list[k] + f * list_stride
-    uint32_t *counters;                          // per frame 4 words: [0] groups, [1 + level % 3] list lengths
+    // per frame 4 counters, each on its own 128-byte line (kGroupCtrPad words apart: atomics on
+    // one line serialise chip-wide, and every wave of every frame appends): counter c of frame f
+    // at counters[(4 f + c) * kGroupCtrPad]; c = 0 groups, 1 + level % 3 list lengths
+    uint32_t *counters;
 };
 
 // appends `v` for the lanes with `yes` to an array with length counter `count`: one atomic
@@ -68,22 +73,70 @@ __device__ __forceinline__ void adaptive_visit(const AdaptiveArgs &a, uint32_t f
         if (leaf || depth >= a.min_splits) {
             uint32_t mn[3] = {255, 255, 255}, mx[3] = {0, 0, 0};
             unsigned long long s64[3] = {0, 0, 0};
-            for (uint32_t yy = n.y; yy < n.y + n.h; ++yy) {
-                const uint8_t *p = a.px[f] + (size_t)yy * a.stride + (size_t)n.x * a.ch;
-                for (uint32_t xx = 0; xx < n.w; ++xx, p += a.ch) {
+            // RGB8 rows that start on a 4-byte boundary are read a dword at a time (a byte load
+            // moves one byte per lane and instruction; the tree's rectangles are 7..8 x 4 pixels
+            // at the seed depth, 96 byte loads a thread).  Twelve bytes = four pixels = three
+            // dwords repeat the byte -> channel pattern, so the slots t[r], r = byte offset from
+            // the first dword mod 3, are static in the unrolled body; they are turned into
+            // channels once at the end (channel = (r + first dword's offset) mod 3).
+            const bool by_dwords = a.ch == 3u && ((reinterpret_cast<uintptr_t>(a.px[f]) | a.stride) & 3u) == 0u;
+            if (by_dwords) {
+                const uint32_t b0 = n.x * 3u, b1 = (n.x + n.w) * 3u, a0 = b0 & ~3u; // bytes of the row
+                uint32_t tmn[3] = {255, 255, 255}, tmx[3] = {0, 0, 0}, tsum[3] = {0, 0, 0};
+                for (uint32_t yy = n.y; yy < n.y + n.h; ++yy) {
+                    const uint8_t *row = a.px[f] + (size_t)yy * a.stride;
+                    for (uint32_t o = a0; o < b1; o += 12u) {
+                        uint32_t dw[3]; // the three loads go out together
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        const uint32_t v = p[k];
-                        sum[k] += v;
-                        mn[k] = min(mn[k], v);
-                        mx[k] = max(mx[k], v);
+                        for (uint32_t i = 0; i < 3; ++i)
+                            dw[i] = o + 4u * i < b1 ? *reinterpret_cast<const uint32_t *>(row + o + 4u * i) : 0u;
+#pragma unroll
+                        for (uint32_t i = 0; i < 3; ++i)
+#pragma unroll
+                            for (uint32_t k = 0; k < 4; ++k) {
+                                const uint32_t od = o + 4u * i;
+                                const uint32_t r = (4u * i + k) % 3u, v = (dw[i] >> (8u * k)) & 0xffu;
+                                const bool in = od + k >= b0 && od + k < b1;
+                                tsum[r] += in ? v : 0u;
+                                tmn[r] = min(tmn[r], in ? v : 255u);
+                                tmx[r] = max(tmx[r], in ? v : 0u);
+                            }
+                    }
+                    if ((yy & 127u) == 127u) { // 128 rows x 65535 px x 255 still fit 32 bits
+                        const uint32_t ph = a0 % 3u;
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) { // channel k sits in slot (k - ph) mod 3
+                            const uint32_t t = ph == 0u ? tsum[k] : ph == 1u ? tsum[(k + 2) % 3] : tsum[(k + 1) % 3];
+                            s64[k] += t;
+                        }
+                        tsum[0] = tsum[1] = tsum[2] = 0;
                     }
                 }
-                if ((yy & 127u) == 127u) { // 128 rows x 65535 px x 255 still fit 32 bits
+                const uint32_t ph = a0 % 3u;
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        s64[k] += sum[k];
-                        sum[k] = 0;
+                for (int k = 0; k < 3; ++k) {
+                    sum[k] = ph == 0u ? tsum[k] : ph == 1u ? tsum[(k + 2) % 3] : tsum[(k + 1) % 3];
+                    mn[k] = ph == 0u ? tmn[k] : ph == 1u ? tmn[(k + 2) % 3] : tmn[(k + 1) % 3];
+                    mx[k] = ph == 0u ? tmx[k] : ph == 1u ? tmx[(k + 2) % 3] : tmx[(k + 1) % 3];
+                }
+            } else {
+                for (uint32_t yy = n.y; yy < n.y + n.h; ++yy) {
+                    const uint8_t *p = a.px[f] + (size_t)yy * a.stride + (size_t)n.x * a.ch;
+                    for (uint32_t xx = 0; xx < n.w; ++xx, p += a.ch) {
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            const uint32_t v = p[k];
+                            sum[k] += v;
+                            mn[k] = min(mn[k], v);
+                            mx[k] = max(mx[k], v);
+                        }
+                    }
+                    if ((yy & 127u) == 127u) { // 128 rows x 65535 px x 255 still fit 32 bits
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            s64[k] += sum[k];
+                            sum[k] = 0;
+                        }
                     }
                 }
             }
@@ -102,7 +155,7 @@ __device__ __forceinline__ void adaptive_visit(const AdaptiveArgs &a, uint32_t f
             }
         }
     }
-    wave_append(live && leaf, a.groups[f], &a.counters[4u * f], g);
+    wave_append(live && leaf, a.groups[f], &a.counters[4u * f * kGroupCtrPad], g);
     const bool split = live && !leaf;
     GroupNode c0 = n, c1 = n;
     if (n.w >= n.h) {
@@ -160,7 +213,7 @@ __global__ __launch_bounds__(256) void adaptive_seed_kernel(AdaptiveArgs a)
             }
         }
         adaptive_visit(a, f, live, n, depth, a.list[(a.seed_depth + 1) % 3] + f * a.list_stride,
-                       &a.counters[4u * f + 1 + (a.seed_depth + 1) % 3]);
+                       &a.counters[(4u * f + 1 + (a.seed_depth + 1) % 3) * kGroupCtrPad]);
     }
 }
 
@@ -170,10 +223,10 @@ __global__ __launch_bounds__(256) void adaptive_seed_kernel(AdaptiveArgs a)
 __global__ __launch_bounds__(256) void adaptive_level_kernel(AdaptiveArgs a, uint32_t depth)
 {
     const uint32_t f = blockIdx.y;
-    uint32_t *counters = a.counters + 4u * f;
-    const uint32_t count = counters[1 + depth % 3];
+    uint32_t *counters = a.counters + 4u * f * kGroupCtrPad;
+    const uint32_t count = counters[(1 + depth % 3) * kGroupCtrPad];
     if (blockIdx.x == 0 && threadIdx.x == 0)
-        counters[1 + (depth + 2) % 3] = 0;
+        counters[(1 + (depth + 2) % 3) * kGroupCtrPad] = 0;
     const uint32_t rounds = (count + gridDim.x * 256 - 1) / (gridDim.x * 256);
     const GroupNode *in = a.list[depth % 3] + f * a.list_stride;
     for (uint32_t r = 0; r < rounds; ++r) {
@@ -181,7 +234,7 @@ __global__ __launch_bounds__(256) void adaptive_level_kernel(AdaptiveArgs a, uin
         const bool live = i < count;
         const GroupNode n = live ? in[i] : GroupNode{0, 0, 1, 1};
         adaptive_visit(a, f, live, n, depth, a.list[(depth + 1) % 3] + f * a.list_stride,
-                       &counters[1 + (depth + 1) % 3]);
+                       &counters[(1 + (depth + 1) % 3) * kGroupCtrPad]);
     }
 }
 
