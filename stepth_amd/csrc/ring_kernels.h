@@ -1109,11 +1109,16 @@ __global__ __launch_bounds__(256) void paint_list_kernel(PaintArgs a)
         return;
     const uint8_t v = lut[a.raw[(size_t)f * a.raw_stride + g]];
     const uint32_t w = min(r.w, a.w - r.x), h = min(r.h, a.h - r.y);
-    const size_t cells = (size_t)w * h;
-    uint8_t *out = a.out[f];
-    for (size_t i = sub; i < cells; i += 16u) {
-        const uint32_t yy = r.y + (uint32_t)(i / w), xx = r.x + (uint32_t)(i % w);
+    uint8_t *out = a.out[f] + (size_t)r.y * a.ostride + r.x;
+    // cells sub, sub + 16, ... of the rectangle in row-major order: one division, then steps
+    uint32_t yy = sub / w, xx = sub - yy * w;
+    while (yy < h) {
         out[(size_t)yy * a.ostride + xx] = v;
+        xx += 16u;
+        while (xx >= w) {
+            xx -= w;
+            ++yy;
+        }
     }
 }
 
