@@ -180,7 +180,8 @@ __global__ __launch_bounds__(256) void sad_search_kernel(SadArgs a)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1)
         m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
-    if (lane == 0 && m)
+    // (a plain read first: most waves cannot raise the max, and atomics on one line serialise)
+    if (lane == 0 && m > __hip_atomic_load(a.max_word + blockIdx.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
         atomicMax(a.max_word + blockIdx.z, m);
 }
 
@@ -242,7 +243,8 @@ __global__ __launch_bounds__(256) void sad_match_kernel(SadArgs a)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1)
         m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
-    if ((threadIdx.x & 63) == 0 && m)
+    if ((threadIdx.x & 63) == 0 &&
+        m > __hip_atomic_load(a.max_word + blockIdx.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
         atomicMax(a.max_word + blockIdx.z, m);
 }
 
