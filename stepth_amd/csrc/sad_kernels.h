@@ -108,10 +108,11 @@ __global__ __launch_bounds__(256) void sad_search_kernel(SadArgs a)
         // + k -> R(x - RAD + i - d) with k = i + (DC-1-j), d = d0 + j
         const uint32_t *rcol = a.rp + (size_t)f * a.rplane_stride + x + kSadPadD + ((int)a.d_max - 1) -
                                d0 - (DC - 1);
-        uint32_t cost[DC], ring[WIN][DC];
+        uint32_t cost[DC], run[DC], ring[WIN][DC];
 #pragma unroll
         for (int j = 0; j < DC; ++j) {
             cost[j] = 0;
+            run[j] = 0;
 #pragma unroll
             for (int s = 0; s < WIN; ++s)
                 ring[s][j] = 0;
@@ -134,25 +135,56 @@ __global__ __launch_bounds__(256) void sad_search_kernel(SadArgs a)
                         r[k] = rr[k];
 #pragma unroll
                     for (int j = 0; j < DC; ++j) {
-                        uint32_t hsum = 0;
+                        // run[j] = sum of the horizontal window sums of ALL rows so far (the sad
+                        // chain accumulates straight into it: < 2^16 per row, a strip has < 2^7
+                        // rows); ring[s][j] = its value WIN rows ago
+                        uint32_t acc = run[j];
 #pragma unroll
                         for (int i = 0; i < WIN; ++i)
-                            hsum = __builtin_amdgcn_sad_u8(l[i], r[i + DC - 1 - j], hsum);
-                        cost[j] += hsum - ring[s][j];
-                        ring[s][j] = hsum;
+                            acc = __builtin_amdgcn_sad_u8(l[i], r[i + DC - 1 - j], acc);
+                        run[j] = acc;
+                        cost[j] = acc - ring[s][j];
+                        ring[s][j] = acc;
                     }
                     const int orow = t - 2 * RAD; // output row (relative) completed by this input row
                     if (orow >= 0) {
                         uint32_t best = s_best[wv][orow][lane], pick = s_pick[wv][orow][lane];
+                        if (d0 + DC <= (int)a.d_max) {
+                            // the chunk's DC disparities at once: the first one under the threshold
+                            // decides; else the first minimum (costs < 2^16, so cost << 4 | j orders
+                            // by cost, then by disparity) if it beats the best so far
+                            static_assert(DC <= 16, "4 bits of disparity in the key");
+                            uint32_t mk = 0xffffffffu;
 #pragma unroll
-                        for (int j = 0; j < DC; ++j) {
-                            const uint32_t d = (uint32_t)(d0 + j), c = cost[j];
-                            const bool live = (int)pick >= 0 && d < a.d_max;
-                            if (live && c < a.thr)
-                                pick = 0x80000000u | d; // first disparity under the threshold
-                            else if (live && c < best) {
-                                best = c;
-                                pick = d;
+                            for (int j = DC - 1; j >= 0; --j)
+                                mk = min(mk, (cost[j] << 4) | (uint32_t)j);
+                            const bool open = (int)pick >= 0;
+                            // the smallest cost tells whether ANY disparity is under the threshold;
+                            // which one is first is only worked out in the chunks where some pixel
+                            // of the wave needs it (neighbouring pixels decide in the same chunks)
+                            if (__builtin_amdgcn_ballot_w64(open && (mk >> 4) < a.thr)) {
+                                uint32_t under = 0;
+#pragma unroll
+                                for (int j = DC - 1; j >= 0; --j)
+                                    under = under + under + (cost[j] < a.thr ? 1u : 0u);
+                                if (open && under)
+                                    pick = 0x80000000u | (uint32_t)(d0 + __builtin_ctz(under));
+                            }
+                            if ((int)pick >= 0 && (mk >> 4) < best) {
+                                best = mk >> 4;
+                                pick = (uint32_t)d0 + (mk & 15u);
+                            }
+                        } else { // the last chunk runs past d_max: disparity by disparity
+#pragma unroll
+                            for (int j = 0; j < DC; ++j) {
+                                const uint32_t d = (uint32_t)(d0 + j), c = cost[j];
+                                const bool live = (int)pick >= 0 && d < a.d_max;
+                                if (live && c < a.thr)
+                                    pick = 0x80000000u | d; // first disparity under the threshold
+                                else if (live && c < best) {
+                                    best = c;
+                                    pick = d;
+                                }
                             }
                         }
                         s_best[wv][orow][lane] = best;
