@@ -302,7 +302,9 @@ def main():
         workers = [make_worker(e_) for e_ in engines]
         # N > 1, contiguous strips: the cut points follow the ranks' measured times from step
         # to step (the cost of a row is data dependent); the warm-up steps let them settle
-        balancer = StripBalancer(H, world, align=8, phase=7, lag=n_slots) if world > 1 and not args.interleave \
+        # (lag 2: a step reads the times of the step before the previous one, which has long
+        # finished -- reading the previous step's would stall the host until its kernels end)
+        balancer = StripBalancer(H, world, align=8, phase=7, lag=max(2, n_slots)) if world > 1 and not args.interleave \
             and not args.no_balance else None
         # N > 1: the gather of a step's rows to rank 0 runs behind the following kernels; the
         # outstanding gathers are flushed inside the timed region
