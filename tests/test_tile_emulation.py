@@ -1,4 +1,5 @@
-"""CPU check of the dense "lane = query" search (stepth_amd/csrc/tile_kernels.h).
+"""CPU check of the "lane = query" searches (stepth_amd/csrc/tile_kernels.h): the dense one for
+one group per pixel and the per-lane one for prepared queries (group lists, tiles, dot arrays).
 
 tests/tools/tile_emulate.cpp compiles the kernel's own per-lane headers (tile_lane.h,
 cell_pack.h) for the host and mirrors the wave-level control flow of ring_tile_kernel with
@@ -29,6 +30,10 @@ def emu(tmp_path_factory):
                                  C.c_void_p, C.c_void_p]
 
     lib.cell_pack_selfcheck.restype = C.c_int
+    lib.list_emulate.restype = C.c_int
+    lib.list_emulate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
+                                 C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.c_void_p]
 
     def run(main, add, prec, max_steps, rows=None):
         main = np.ascontiguousarray(main)
@@ -110,3 +115,62 @@ def test_cell_format_arithmetic_is_the_reference_predicate(emu):
     `|v - what| < precision` on every channel (/root/reference/src/helpers.rs:35): every value
     pair per channel for precisions 0..255, plus 200 000 random three-channel lines"""
     assert emu.lib.cell_pack_selfcheck() == 0
+
+
+def _list_check(emu, oracle, add, cx, cy, what, prec, ms, lanes):
+    """ring_list_kernel's emulation against oracle.match_groups on the same queries (a group
+    {x = 2 cx, y = 2 cy, w = h = 0} has middle (cx, cy), src/depth_image.rs:114-117)"""
+    add = np.ascontiguousarray(add[..., :3])
+    cx, cy = np.ascontiguousarray(cx, np.uint32), np.ascontiguousarray(cy, np.uint32)
+    what = np.ascontiguousarray(what, np.uint8)
+    n = len(cx)
+    d, found, pos = np.zeros(n, np.uint32), np.zeros(n, np.uint8), np.zeros((n, 2), np.uint32)
+    st = (C.c_uint64 * 3)()
+    pr = (C.c_uint8 * 3)(*prec)
+    rc = emu.lib.list_emulate(cx.ctypes.data, cy.ctypes.data, what.ctypes.data, n, add.ctypes.data,
+                              add.shape[1], add.shape[0], C.cast(pr, C.c_void_p), ms, lanes,
+                              d.ctypes.data, found.ctypes.data, pos.ctypes.data, C.cast(st, C.c_void_p))
+    assert rc == 0, f"list_emulate failed with {rc}"
+    g = np.zeros(n, oracle.GROUP_DTYPE)
+    g["x"], g["y"], g["value"] = 2 * cx, 2 * cy, what
+    ref = oracle.match_groups(g, add, ms, prec)
+    assert np.array_equal(found, ref["found"]), np.argwhere(found != ref["found"])[:5]
+    assert np.array_equal(d, ref["raw32"]), np.argwhere(d != ref["raw32"])[:5]
+    hit = found.astype(bool)
+    assert np.array_equal(pos[hit], ref["pos"][hit])
+    return list(st)
+
+
+@pytest.mark.parametrize("lanes", [16, 32, 64])
+def test_list_search_clustered_and_spread_queries(emu, oracle, lanes):
+    """queries sorted by place share one window of superblocks per wave; shuffled ones are spread
+    too far for its slots and walk their own windows -- both paths must give the oracle's answer"""
+    from stepth_amd import synth
+    rng = np.random.default_rng(100 + lanes)
+    l, r, _ = synth.stereo_pair(700, 500, 60, seed=21)
+    n = 1500
+    cx, cy = rng.integers(0, 700, n), rng.integers(0, 500, n)
+    what = l[rng.integers(0, 500, n), rng.integers(0, 700, n)]
+    order = np.lexsort((cx // 32, cy // 32))  # bins of 32x32 cells, as the engine sorts group lists
+    st = _list_check(emu, oracle, r, cx[order], cy[order], what[order], [36] * 3, 128, lanes)
+    st2 = _list_check(emu, oracle, r, cx, cy, what, [36] * 3, 255, lanes)
+    assert st[0] > 0 and st2[1] > 0, (st, st2)  # the shared and the per-lane far phase both ran
+
+
+def test_list_search_edges(emu, oracle):
+    """centres outside the array end at once (src/helpers.rs:49-51), rare matches far away,
+    precision 0, reaches of 1 and 2, a one-row array"""
+    rng = np.random.default_rng(5)
+    add = np.full((300, 420, 3), 90, np.uint8)
+    add[17:19, 400:403] = 200
+    add[290:293, 3:9] = 20
+    n = 400
+    cx, cy = rng.integers(0, 460, n), rng.integers(0, 330, n)  # some beyond 420 x 300
+    what = rng.choice([200, 20, 90, 150], (n, 1)).repeat(3, 1).astype(np.uint8)
+    for ms in (1, 2, 25, 26, 255, 263):
+        _list_check(emu, oracle, add, cx, cy, what, [36] * 3, ms, 64)
+    _list_check(emu, oracle, add, cx, cy, what, [0, 36, 36], 255, 32)
+    _list_check(emu, oracle, add, cx, cy, what, [255] * 3, 255, 16)
+    row = rng.integers(0, 256, (1, 500, 3)).astype(np.uint8) // 64 * 64
+    _list_check(emu, oracle, row, rng.integers(0, 500, 200), np.zeros(200, int),
+                row[0, rng.integers(0, 500, 200)], [20] * 3, 200, 64)

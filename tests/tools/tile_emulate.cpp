@@ -1,4 +1,5 @@
-// tile_emulate.cpp -- CPU emulation of ring_tile_kernel (stepth_amd/csrc/tile_kernels.h).
+// tile_emulate.cpp -- CPU emulation of ring_tile_kernel and ring_list_kernel
+// (stepth_amd/csrc/tile_kernels.h), and a self-check of cell_pack.h's arithmetic.
 //
 // Test infrastructure: runs the kernel's per-lane code (tile_lane.h, cell_pack.h -- the very
 // same headers) and mirrors its wave-level control flow with plain loops over 64 "lanes", so
@@ -24,16 +25,17 @@ struct U2 {
 };
 } // namespace
 
-extern "C" int tile_emulate(const uint8_t *main_px, uint32_t W, uint32_t H, uint32_t mch,
-                            const uint8_t *add, uint32_t wa, uint32_t ha, const uint8_t *prec,
-                            uint32_t max_steps_in, uint32_t row0, uint32_t row1, uint8_t *raw,
-                            uint32_t *max_out, uint64_t *stats /* [3]: probes, lines, steps */)
-{
-    const uint32_t bw = (wa + 7) / 8, bh = (ha + 7) / 8, sbw = (bw + 7) / 8, sbh = (bh + 7) / 8;
-    const uint32_t bwp = tile_bwp(bw), bhp = tile_bhp(bh);
-    std::vector<uint32_t> T((size_t)bw * bh * 64, kNoCell), TT((size_t)bw * bh * 64, kNoCell);
-    std::vector<U2> BBp((size_t)bwp * bhp, U2{0, kNoCell}), SB((size_t)sbw * sbh, U2{0, kNoCell});
-    std::vector<U2> LB((size_t)bw * bh * 16, U2{0, kNoCell}); // per block: 8 row bounds, 8 column bounds
+// the packed additional image (tile_pack_kernel / tile_super_kernel), built on the CPU
+struct Packed {
+    uint32_t wa, ha, bw, bh, sbw, sbh, bwp, bhp;
+    std::vector<uint32_t> T, TT;
+    std::vector<U2> BBp, SB, LB;
+    Packed(const uint8_t *add, uint32_t wa_, uint32_t ha_)
+        : wa(wa_), ha(ha_), bw((wa_ + 7) / 8), bh((ha_ + 7) / 8), sbw((bw + 7) / 8), sbh((bh + 7) / 8),
+          bwp(tile_bwp(bw)), bhp(tile_bhp(bh)), T((size_t)bw * bh * 64, kNoCell), TT((size_t)bw * bh * 64, kNoCell),
+          BBp((size_t)bwp * bhp, U2{0, kNoCell}), SB((size_t)sbw * sbh, U2{0, kNoCell}),
+          LB((size_t)bw * bh * 16, U2{0, kNoCell}) // per block: 8 row bounds, 8 column bounds
+    {
     // pack (tile_pack_kernel / tile_super_kernel)
     for (uint32_t by = 0; by < bh; ++by)
         for (uint32_t bx = 0; bx < bw; ++bx) {
@@ -90,6 +92,18 @@ extern "C" int tile_emulate(const uint8_t *main_px, uint32_t W, uint32_t H, uint
             SB[(size_t)sy * sbw + sx] = U2{pack_cell(mx[0], mx[1], mx[2]), pack_cell(mn[0], mn[1], mn[2])};
         }
 
+    }
+};
+
+extern "C" int tile_emulate(const uint8_t *main_px, uint32_t W, uint32_t H, uint32_t mch,
+                            const uint8_t *add, uint32_t wa, uint32_t ha, const uint8_t *prec,
+                            uint32_t max_steps_in, uint32_t row0, uint32_t row1, uint8_t *raw,
+                            uint32_t *max_out, uint64_t *stats /* [3]: probes, lines, steps */)
+{
+    const Packed P(add, wa, ha);
+    const uint32_t bw = P.bw, bh = P.bh, sbw = P.sbw, bwp = P.bwp;
+    const std::vector<uint32_t> &T = P.T, &TT = P.TT;
+    const std::vector<U2> &BBp = P.BBp, &SB = P.SB, &LB = P.LB;
     const uint32_t max_steps = std::min(max_steps_in, std::max(wa, ha));
     const uint32_t top = std::max(max_steps, 2u) - 1u;
     uint32_t pb = 1;
@@ -191,6 +205,14 @@ extern "C" int tile_emulate(const uint8_t *main_px, uint32_t W, uint32_t H, uint
                                 break;
                             const auto itmin = std::min_element(skeys.begin(), skeys.end());
                             const uint32_t pick = *itmin;
+                            // the kernel stops at the first slot beyond the largest limit + 2 (slots
+                            // are keyed by the distance from the middle of the wave's 4x4 centres,
+                            // which is within 2 rings of every lane's own distance)
+                            uint32_t maxlimit = 0;
+                            for (int l = 0; l < 64; ++l)
+                                maxlimit = std::max(maxlimit, q[l].limit);
+                            if ((pick >> 8) >= maxlimit + 2u)
+                                break;
                             skeys.erase(itmin);
                             const int sx = sx0 + (int)(pick & 15u), sy = sy0 + (int)((pick >> 4) & 15u);
                             const U2 sb = SB[(size_t)sy * sbw + sx];
@@ -332,6 +354,219 @@ extern "C" int cell_pack_selfcheck(void)
         t.load(cells, lo, hi);
         if (t.any() != (want_bits != 0) || t.bits() != want_bits)
             return 6;
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// CPU emulation of ring_list_kernel (prepared queries: group lists, tiles > 1x1,
+// stepth_distance_dot_array_batch): the same per-lane headers, the kernel's wave-level control
+// flow mirrored with loops over the `lanes` (16, 32 or 64) queries a wave takes -- the lane's
+// own 7x7 window, then either the wave-shared window of superblocks (visited nearest first
+// from the middle of the wave's centres, with the kernel's tolerance and early exit) or, for a
+// spread-out wave, the lane's own ring walk.  Query k: centre (cx[k], cy[k]), colour what[3k..].
+// Outputs per query: d (distance), found, pos (x, y).  Returns 0, or < 0 where the GPU would fault.
+// ---------------------------------------------------------------------------------------
+extern "C" int list_emulate(const uint32_t *cx, const uint32_t *cy, const uint8_t *what, uint32_t n,
+                            const uint8_t *add, uint32_t wa, uint32_t ha, const uint8_t *prec,
+                            uint32_t max_steps_in, uint32_t lanes, uint32_t *d_out, uint8_t *found_out,
+                            uint32_t *pos_out, uint64_t *stats /* [3]: shared far waves, per-lane far waves, probes */)
+{
+    static const uint64_t kNearLe[4] = {0x0000000008000000ull, 0x0000001C1C1C0000ull, 0x00003E3E3E3E3E00ull,
+                                        0x007F7F7F7F7F7F7Full};
+    if (lanes != 16 && lanes != 32 && lanes != 64)
+        return -3;
+    const Packed P(add, wa, ha);
+    const uint32_t max_steps = std::min(max_steps_in, std::max(wa, ha));
+    const uint32_t top = std::max(max_steps, 2u) - 1u;
+    uint32_t pb = 1;
+    while ((2u * top) >> pb)
+        ++pb;
+    const uint32_t ring_shift = pb + 2;
+    uint64_t n_shared = 0, n_own = 0, n_probes = 0;
+    int fault = 0;
+
+    for (uint32_t w0 = 0; w0 < n; w0 += lanes) {
+        const uint32_t nl = std::min(lanes, n - w0);
+        LaneQ q[64];
+        uint32_t s_end[64];
+        int cbx[64], cby[64];
+        for (uint32_t l = 0; l < nl; ++l) {
+            const uint32_t k = w0 + l;
+            q[l].qx = (int)cx[k];
+            q[l].qy = (int)cy[k];
+            make_box(what + 3 * k, prec, q[l].lo, q[l].hi);
+            q[l].best = kTileNoKey;
+            q[l].limit = 0;
+            s_end[l] = 0;
+            cbx[l] = (int)(cx[k] >> 3);
+            cby[l] = (int)(cy[k] >> 3);
+            if (cx[k] < wa && cy[k] < ha && max_steps > 0) { // else: the search ends at once (helpers.rs:49-51)
+                const uint32_t cell = P.T[((size_t)cby[l] * P.bw + cbx[l]) * 64 + ((cy[k] & 7) << 3) + (cx[k] & 7)];
+                const uint32_t smax = std::max(std::max(cx[k], wa - 1 - cx[k]), std::max(cy[k], ha - 1 - cy[k]));
+                s_end[l] = std::min(max_steps, smax + 1);
+                if (cell_in_box(cell, q[l].lo, q[l].hi))
+                    q[l].best = 0;
+                else if (s_end[l] > 1)
+                    q[l].limit = s_end[l];
+            }
+        }
+        auto bounds_mask = [&](int l, int bx0, int by0) { // the 64 bound tests of a window
+            uint64_t mm = 0;
+            for (int row = 0; row < 8; ++row)
+                for (int col = 0; col < 8; ++col) {
+                    const U2 bb = P.BBp[(size_t)(by0 + kPadB + row) * P.bwp + (size_t)(bx0 + kPadB + col)];
+                    if (box_meets(bb.x, bb.y, q[l].lo, q[l].hi))
+                        mm |= 1ull << (row * 8 + col);
+                }
+            return mm;
+        };
+        auto probe_candidates = [&](int l, uint64_t cur, int bx0, int by0) {
+            while (cur) {
+                const int k = __builtin_ctzll(cur);
+                cur &= cur - 1;
+                const int bx = bx0 + (k & 7), by = by0 + (k >> 3);
+                const int x0 = bx * 8 - q[l].qx, y0 = by * 8 - q[l].qy;
+                if ((uint32_t)square_dmin(x0, y0, 8) < q[l].limit) {
+                    if (bx < 0 || by < 0 || bx >= (int)P.bw || by >= (int)P.bh) {
+                        fault = -2; // a padded block got through
+                        return;
+                    }
+                    const size_t boff = ((size_t)by * P.bw + bx) * 64;
+                    probe_block(q[l], x0, y0, pb, &P.T[boff], &P.TT[boff], reinterpret_cast<const uint32_t *>(&P.LB[boff / 4]));
+                    ++n_probes;
+                }
+            }
+        };
+        // ---- the lane's own 7x7 window ----
+        for (uint32_t l = 0; l < nl; ++l) {
+            if (q[l].limit == 0)
+                continue;
+            if (cby[l] - 3 + kPadB < 0 || cbx[l] - 3 + kPadB < 0 || cby[l] + 4 + kPadB >= (int)P.bhp + 1 ||
+                cbx[l] + 4 + kPadB >= (int)P.bwp + 1)
+                return -4; // the window would leave the padded bounds
+            const uint64_t cand = bounds_mask((int)l, cbx[l] - 3, cby[l] - 3) & kNearLe[3];
+            for (int ps = 0; ps < 4; ++ps) {
+                if (8 * (ps - 1) + 1 >= (int)q[l].limit)
+                    break;
+                probe_candidates((int)l, cand & kNearLe[ps] & ~(ps ? kNearLe[ps - 1] : 0ull), cbx[l] - 3, cby[l] - 3);
+            }
+            if (s_end[l] <= 25 || (q[l].best != kTileNoKey && (q[l].best >> ring_shift) <= 24))
+                q[l].limit = 0;
+        }
+        // ---- far phase ----
+        bool any_far = false;
+        int wx_lo = 0x7fffffff, wy_lo = 0x7fffffff, wx_hi = 0, wy_hi = 0;
+        for (uint32_t l = 0; l < nl; ++l)
+            if (q[l].limit != 0) {
+                any_far = true;
+                wx_lo = std::min(wx_lo, q[l].qx), wy_lo = std::min(wy_lo, q[l].qy);
+                wx_hi = std::max(wx_hi, q[l].qx), wy_hi = std::max(wy_hi, q[l].qy);
+            }
+        if (any_far) {
+            const int R = (int)max_steps - 1;
+            const int sx0 = std::max(wx_lo - R, 0) >> 6, sy0 = std::max(wy_lo - R, 0) >> 6;
+            const int sx1 = std::min(wx_hi + R, (int)wa - 1) >> 6, sy1 = std::min(wy_hi + R, (int)ha - 1) >> 6;
+            const int nsx = sx1 - sx0 + 1, nsy = sy1 - sy0 + 1;
+            if (nsx <= 10 && nsy <= 12) {
+                ++n_shared;
+                const int mx = (wx_lo + wx_hi) >> 1, my = (wy_lo + wy_hi) >> 1;
+                const uint32_t tol = (uint32_t)std::max(wx_hi - mx, wy_hi - my) + 1u;
+                std::vector<uint32_t> skeys;
+                for (int ty = 0; ty < nsy; ++ty)
+                    for (int tx = 0; tx < nsx; ++tx) {
+                        const int sx = sx0 + tx, sy = sy0 + ty;
+                        const U2 sb = P.SB[(size_t)sy * P.sbw + sx];
+                        bool anyw = false;
+                        for (uint32_t l = 0; l < nl; ++l) {
+                            const uint32_t dS = (uint32_t)square_dmin((sx << 6) - q[l].qx, (sy << 6) - q[l].qy, 64);
+                            anyw |= dS < q[l].limit && box_meets(sb.x, sb.y, q[l].lo, q[l].hi);
+                        }
+                        if (anyw)
+                            skeys.push_back(((uint32_t)square_dmin((sx << 6) - mx, (sy << 6) - my, 64) << 8) |
+                                            (uint32_t)(ty * 16 + tx));
+                    }
+                while (!skeys.empty()) {
+                    const auto itmin = std::min_element(skeys.begin(), skeys.end());
+                    const uint32_t pick = *itmin;
+                    uint32_t maxlimit = 0;
+                    for (uint32_t l = 0; l < nl; ++l)
+                        maxlimit = std::max(maxlimit, q[l].limit);
+                    if ((pick >> 8) >= maxlimit + tol)
+                        break;
+                    skeys.erase(itmin);
+                    const int sx = sx0 + (int)(pick & 15u), sy = sy0 + (int)((pick >> 4) & 15u);
+                    const U2 sb = P.SB[(size_t)sy * P.sbw + sx];
+                    for (uint32_t l = 0; l < nl; ++l) {
+                        const uint32_t dS = (uint32_t)square_dmin((sx << 6) - q[l].qx, (sy << 6) - q[l].qy, 64);
+                        if (!(dS < q[l].limit && box_meets(sb.x, sb.y, q[l].lo, q[l].hi)))
+                            continue;
+                        const int bx0 = sx * 8, by0 = sy * 8;
+                        probe_candidates((int)l, bounds_mask((int)l, bx0, by0) & ~window_le_mask(bx0, by0, cbx[l], cby[l], 3),
+                                         bx0, by0);
+                    }
+                }
+            } else {
+                ++n_own;
+                for (int ring = 0, t = 0;; ++t) {
+                    const int n_in_ring = ring == 0 ? 1 : 8 * ring;
+                    if (t >= n_in_ring) {
+                        t = 0;
+                        ++ring;
+                    }
+                    const int lb = ring == 0 ? 0 : 64 * (ring - 1) + 1;
+                    bool go = false;
+                    for (uint32_t l = 0; l < nl; ++l)
+                        go |= q[l].limit != 0 && lb < (int)q[l].limit;
+                    if (!go)
+                        break;
+                    int dx = 0, dy = 0;
+                    if (ring > 0) {
+                        const int side = t / (2 * ring), o = t - side * 2 * ring;
+                        dx = side == 0 ? -ring + o : side == 1 ? ring : side == 2 ? ring - o : -ring;
+                        dy = side == 0 ? -ring : side == 1 ? -ring + o : side == 2 ? ring : ring - o;
+                    }
+                    for (uint32_t l = 0; l < nl; ++l) {
+                        const int lx0 = std::max(q[l].qx - R, 0) >> 6, ly0 = std::max(q[l].qy - R, 0) >> 6;
+                        const int lx1 = std::min(q[l].qx + R, (int)wa - 1) >> 6, ly1 = std::min(q[l].qy + R, (int)ha - 1) >> 6;
+                        const int sx = (q[l].qx >> 6) + dx, sy = (q[l].qy >> 6) + dy;
+                        if (!(q[l].limit != 0 && sx >= lx0 && sx <= lx1 && sy >= ly0 && sy <= ly1))
+                            continue;
+                        const U2 sb = P.SB[(size_t)sy * P.sbw + sx];
+                        const uint32_t dS = (uint32_t)square_dmin((sx << 6) - q[l].qx, (sy << 6) - q[l].qy, 64);
+                        if (!(dS < q[l].limit && box_meets(sb.x, sb.y, q[l].lo, q[l].hi)))
+                            continue;
+                        const int bx0 = sx * 8, by0 = sy * 8;
+                        probe_candidates((int)l, bounds_mask((int)l, bx0, by0) & ~window_le_mask(bx0, by0, cbx[l], cby[l], 3),
+                                         bx0, by0);
+                    }
+                }
+            }
+        }
+        if (fault)
+            return fault;
+        for (uint32_t l = 0; l < nl; ++l) {
+            const uint32_t k = w0 + l;
+            const bool fnd = q[l].best != kTileNoKey;
+            int ddx = 0, ddy = 0;
+            uint32_t d = 0;
+            if (fnd && q[l].best != 0) {
+                const int s = (int)(q[l].best >> (pb + 2)), side = (int)((q[l].best >> pb) & 3);
+                const int off = (int)(q[l].best & ((1u << pb) - 1)) - s;
+                ddx = side < 2 ? off : side == 2 ? s : -s;
+                ddy = side == 0 ? s : side == 1 ? -s : off;
+                d = isqrt_floor((uint32_t)(ddx * ddx + ddy * ddy));
+            }
+            d_out[k] = d;
+            found_out[k] = fnd ? 1 : 0;
+            pos_out[2 * k] = fnd ? (uint32_t)(q[l].qx + ddx) : 0;
+            pos_out[2 * k + 1] = fnd ? (uint32_t)(q[l].qy + ddy) : 0;
+        }
+    }
+    if (stats) {
+        stats[0] = n_shared;
+        stats[1] = n_own;
+        stats[2] = n_probes;
     }
     return 0;
 }
