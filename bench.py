@@ -29,7 +29,8 @@ Extra objects (N = 1, outside the timed region, each a few launches): `two_strea
 `config2_1080p_d64`, `config3_4k_d128` (north_star's target configuration),
 `config5_8k_d256_1gpu`, `asset_tiled_1080p` (the reference's own image pair, mirror-tiled),
 `adaptive_flow` (grouping -> match -> normalise -> paint, the way the reference runs),
-`end_to_end` (host-resident frames, PCIe-inclusive), `sad_mode`, `with_gaussian_tail`,
+`end_to_end` (host-resident frames, PCIe-inclusive), `sad_mode` and `sad_config*` (the windowed-SAD
+mode on the headline frames and on BASELINE's configurations read literally), `with_gaussian_tail`,
 `foreground_tail`.  Every ring leg carries its own kernel time, Mpixels/s, HBM fraction and a
 bit-exact flag against the oracle (whole frame 0 at 1080p, 20 000 sampled pixels above).
 """
@@ -149,6 +150,48 @@ def sampled_raw_check(O, raw_gpu, main, add, prec, max_steps, n=20000, seed=1):
     g["value"] = main[ys, xs, :3]
     res = O.match_groups(g, add, max_steps, prec)
     return bool(np.array_equal(res["raw"], raw_gpu[ys, xs])), res["probes"] / n
+
+
+def sad_leg(eng, O, frames_np, prec, d_max, win, reps, dev, label):
+    """the engine's windowed-SAD mode (north_star's literal wording; not in the reference) on
+    device-resident frames, one batched call per repetition; a 16-row band of frame 0 is
+    compared with the CPU statement of the same mode (oracle.sad_rows)"""
+    from stepth_amd import MODE_SAD_WINDOW
+    from stepth_amd.engine import PlaneList
+    h, w = frames_np[0][0].shape[:2]
+    mains = [torch.from_numpy(l).to(dev) for l, _ in frames_np]
+    adds = [torch.from_numpy(r).to(dev) for _, r in frames_np]
+    outs = [torch.empty((h, w), dtype=torch.uint8, device=dev) for _ in frames_np]
+    n = len(frames_np)
+    pm, pa, po = PlaneList(mains, (3, 4), "main"), PlaneList(adds, (3,), "additional"), PlaneList(outs, (1,), "depth")
+
+    def call(**kw):
+        return eng.depth_from_additional_batch(pm, pa, prec, mode=MODE_SAD_WINDOW, d_max=d_max, win=win,
+                                               outs=po, asynchronous=True, **kw)
+    for _ in range(2):
+        call()
+    torch.cuda.synchronize()
+    eng.kernel_time_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        call()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    kms, kl = eng.kernel_time_read()
+    eng.kernel_time_enable(False)
+    k_avg = kms / max(kl, 1)
+    px = n * w * h
+    out = {"value": round(px / dt / 1e6, 1), "unit": "Mpixels/s", "workload": label,
+           "frames_per_launch": n // max(kl // reps, 1), "ms_per_call": round(dt * 1e3, 4),
+           "kernel": "sad_search_kernel", "kernel_avg_ms": round(k_avg, 4),
+           "hbm_frac": round(ALGO_BYTES_PER_PIXEL * px / max(kl // reps, 1) / (k_avg * 1e-3) / 1e9
+                             / HBM_PEAK_GBS, 6)}
+    r0 = (h // 2) & ~15
+    raw, _ = eng.depth_from_additional_batch(mains[:1], adds[:1], prec, mode=MODE_SAD_WINDOW, d_max=d_max,
+                                             win=win, raw_only=True)
+    ref = O.sad_rows(frames_np[0][0], frames_np[0][1], d_max, win, prec, r0, r0 + 16)
+    out["parity_16_row_band_bit_exact"] = bool(np.array_equal(raw[0][r0:r0 + 16].cpu().numpy(), ref[r0:r0 + 16]))
+    return out
 
 
 def ring_leg(eng, O, frames_np, prec, max_steps, reps, check, dev, label):
@@ -515,6 +558,15 @@ def main():
                 eng, O, f8k, prec, 256, 3, "sample", dev,
                 "1 x 7680x4320 pair (the 4K synthetic pair mirror-tiled 2x2), ring first-hit, "
                 "max_steps=d_max=256, one frame per launch")
+            # -- BASELINE.json's configurations read literally (an N x N SAD window over d_max
+            # disparities): the engine's second mode, which the reference does not have
+            out["sad_config2_1080p_d64_5x5"] = sad_leg(
+                eng, O, frames_np, prec, 64, 5, 3, dev,
+                f"{n_frames} x 1920x1080 synthetic pairs, windowed SAD 5x5, d_max=64")
+            out["sad_config3_4k_d128_5x5"] = sad_leg(
+                eng, O, f4k, prec, 128, 5, 3, dev, "4 x 3840x2160 synthetic pairs, windowed SAD 5x5, d_max=128")
+            out["sad_config5_8k_d256_9x9"] = sad_leg(
+                eng, O, f8k, prec, 256, 9, 2, dev, "1 x 7680x4320 pair, windowed SAD 9x9, d_max=256")
             del f4k, f8k
         if extra:
             frames = frame_sets[0]
