@@ -42,7 +42,7 @@ struct DevBuf {
 // normalise_rows, [65] pending count, then from word 128 on the kParts run counters of
 // ring_search_kernel
 constexpr uint32_t kWordHostMax = 64, kWordPending = 65, kWordCounters = 128;
-constexpr size_t kStatsBytes = 256; // 8 documented counters + raw slots of tuning builds
+constexpr size_t kStatsBytes = (size_t)kStatsWords * kStatsReplicas * 8; // replicated counters (ring_kernels.h)
 constexpr size_t kWordsBytes = (kWordCounters + kParts * kPartStride) * 4;
 static_assert(kMaxBatch <= (int)kWordHostMax, "per-frame max words");
 
@@ -1950,15 +1950,28 @@ int stepth_stats_enable(stepth_engine *e, int enable)
     return STEPTH_OK;
 }
 
+// the sum of the counters' replicas (ring_kernels.h stats_replica); synchronises the stream
+static int read_stats(stepth_engine *e, unsigned long long (&sum)[kStatsWords])
+{
+    std::vector<unsigned long long> h((size_t)kStatsWords * kStatsReplicas);
+    HIP_TRY(e, hipMemcpyAsync(h.data(), e->stats, kStatsBytes, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    for (uint32_t w = 0; w < kStatsWords; ++w) {
+        sum[w] = 0;
+        for (uint32_t r = 0; r < kStatsReplicas; ++r)
+            sum[w] += h[(size_t)r * kStatsWords + w];
+    }
+    return STEPTH_OK;
+}
+
 int stepth_get_stats(stepth_engine *e, stepth_stats *out)
 {
     if (!e || !out)
         return STEPTH_ERR_BAD_ARG;
     if (!e->stats_enabled)
         return fail(e, STEPTH_ERR_BAD_ARG, "stats are not enabled (stepth_stats_enable)");
-    unsigned long long h[8] = {0};
-    HIP_TRY(e, hipMemcpyAsync(h, e->stats, 64, hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    unsigned long long h[kStatsWords];
+    TRY(read_stats(e, h));
     out->groups = e->stats_groups;
     out->ring0_hits = h[0];
     out->probes = h[1];
@@ -1971,10 +1984,12 @@ int stepth_get_stats(stepth_engine *e, stepth_stats *out)
 
 int stepth_get_stats_raw(stepth_engine *e, uint64_t *out, uint32_t n)
 {
-    if (!e || !out || n > kStatsBytes / 8)
+    if (!e || !out || n > kStatsWords)
         return STEPTH_ERR_BAD_ARG;
-    HIP_TRY(e, hipMemcpyAsync(out, e->stats, (size_t)n * 8, hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    unsigned long long h[kStatsWords];
+    TRY(read_stats(e, h));
+    for (uint32_t w = 0; w < n; ++w)
+        out[w] = h[w];
     return STEPTH_OK;
 }
 

@@ -387,8 +387,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void ring
             v7 += __shfl_xor(v7, o, 64);
         }
         if (lane == 0) {
-            atomicAdd(&a.stats[0], v0);
-            atomicAdd(&a.stats[1], v1);
+            atomicAdd(&stats_replica(a.stats)[0], v0);
+            atomicAdd(&stats_replica(a.stats)[1], v1);
 #if defined(STEPTH_TILE_PROFILE) && STEPTH_TILE_PROFILE == 2
         }
         for (int i = 0; i < 7; ++i) { // raw slots 8.. : lane counts, 16.. : wave counts
@@ -398,27 +398,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void ring
                 wv2 += __shfl_xor(wv2, o, 64);
             }
             if (lane == 0) {
-                atomicAdd(&a.stats[8 + i], lv);
-                atomicAdd(&a.stats[16 + i], wv2);
+                atomicAdd(&stats_replica(a.stats)[8 + i], lv);
+                atomicAdd(&stats_replica(a.stats)[16 + i], wv2);
             }
         }
         if (lane == 0) {
-            atomicAdd(&a.stats[2], n_near);
-            atomicAdd(&a.stats[3], n_survey);
-            atomicAdd(&a.stats[4], n_super);
-            atomicAdd(&a.stats[5], v5);
+            atomicAdd(&stats_replica(a.stats)[2], n_near);
+            atomicAdd(&stats_replica(a.stats)[3], n_survey);
+            atomicAdd(&stats_replica(a.stats)[4], n_super);
+            atomicAdd(&stats_replica(a.stats)[5], v5);
 #elif defined(STEPTH_TILE_PROFILE)
-            atomicAdd(&a.stats[2], pc_tests);
-            atomicAdd(&a.stats[3], pc_survey);
-            atomicAdd(&a.stats[4], pc_probe);
-            atomicAdd(&a.stats[5], STEPTH_TICK() - pc_t0);
+            atomicAdd(&stats_replica(a.stats)[2], pc_tests);
+            atomicAdd(&stats_replica(a.stats)[3], pc_survey);
+            atomicAdd(&stats_replica(a.stats)[4], pc_probe);
+            atomicAdd(&stats_replica(a.stats)[5], STEPTH_TICK() - pc_t0);
 #else
-            atomicAdd(&a.stats[2], n_near);
-            atomicAdd(&a.stats[3], n_survey);
-            atomicAdd(&a.stats[4], n_super);
-            atomicAdd(&a.stats[5], v5);
-            atomicAdd(&a.stats[6], n_super_empty); // raw slots (stepth_get_stats_raw)
-            atomicAdd(&a.stats[7], v7);
+            atomicAdd(&stats_replica(a.stats)[2], n_near);
+            atomicAdd(&stats_replica(a.stats)[3], n_survey);
+            atomicAdd(&stats_replica(a.stats)[4], n_super);
+            atomicAdd(&stats_replica(a.stats)[5], v5);
+            atomicAdd(&stats_replica(a.stats)[6], n_super_empty); // raw slots (stepth_get_stats_raw)
+            atomicAdd(&stats_replica(a.stats)[7], v7);
 #endif
         }
     }
@@ -762,11 +762,11 @@ __global__ __launch_bounds__(256) void ring_list_kernel(ListArgs a)
             v5 += __shfl_xor(v5, o, 64);
         }
         if (lane == 0) {
-            atomicAdd(&a.stats[0], v0);
-            atomicAdd(&a.stats[1], v1);
-            atomicAdd(&a.stats[2], v2);
-            atomicAdd(&a.stats[4], v4);
-            atomicAdd(&a.stats[5], v5);
+            atomicAdd(&stats_replica(a.stats)[0], v0);
+            atomicAdd(&stats_replica(a.stats)[1], v1);
+            atomicAdd(&stats_replica(a.stats)[2], v2);
+            atomicAdd(&stats_replica(a.stats)[4], v4);
+            atomicAdd(&stats_replica(a.stats)[5], v5);
         }
     }
 }
