@@ -360,8 +360,8 @@ int stepth_get_stats(stepth_engine *engine, stepth_stats *out);
 int stepth_get_stats_raw(stepth_engine *engine, uint64_t *out, uint32_t n);
 
 /*
- * Timing hook for bench.py's roofline leg: brackets the dominant kernel (ring_search or
- * sad_match) of every subsequent call with HIP events on the engine's stream and
+ * Timing hook for bench.py's roofline leg: brackets the dominant kernel (the ring search or
+ * the SAD search) of every subsequent call with HIP events on the engine's stream and
  * accumulates; stepth_kernel_time_read() synchronises and returns the sum in milliseconds
  * and the number of launches, then resets.
  */

@@ -19,7 +19,7 @@
 //   All 64 queries of a wave have their centre in the same 8x8-cell block of the additional
 //   image, so the wave walks ONE sequence of blocks: their bounds arrive by scalar loads
 //   (s_load_dwordx16 = a row of 8 blocks) and each lane tests them against its own colour box
-//   -- 5 VALU instructions per block for 64 queries, against ~70 per 64 blocks for <= 4
+//   -- 4 VALU instructions per block for 64 queries, against ~70 per 64 blocks for <= 4
 //   queries before.  Blocks that pass are probed by the lane itself, a line of 8 cells at a
 //   time, nearest line first (tile_lane.h), with an early exit at the first hit.
 //
