@@ -1199,9 +1199,15 @@ static int batch_sad(stepth_engine *e, uint32_t n_frames, const stepth_image *ma
         pa.tile_w = pa.tile_h = 1;
         pa.gx = W;
         pa.n = W * rows;
-        const size_t total = (size_t)rows * W;
-        hipLaunchKernelGGL(paint_tiles_kernel, dim3((uint32_t)std::min<size_t>((total + 255) / 256, 1024), nf),
-                           dim3(256), 0, e->stream, pa);
+        bool vec4 = (W & 3u) == 0 && (pa.ostride & 3u) == 0; // four pixels per thread where they align
+        for (uint32_t f = 0; f < nf; ++f)
+            vec4 = vec4 && (reinterpret_cast<uintptr_t>(pa.out[f]) & 3u) == 0;
+        const size_t total = (size_t)rows * (vec4 ? W / 4 : W);
+        const dim3 pgrid((uint32_t)std::min<size_t>((total + 255) / 256, 1024), nf);
+        if (vec4)
+            hipLaunchKernelGGL(paint_1x1_vec4_kernel, pgrid, dim3(256), 0, e->stream, pa);
+        else
+            hipLaunchKernelGGL(paint_tiles_kernel, pgrid, dim3(256), 0, e->stream, pa);
         HIP_TRY(e, hipGetLastError());
         if (!async) {
             uint32_t mx[kMaxBatch];
