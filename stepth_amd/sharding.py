@@ -147,10 +147,12 @@ class StripBalancer:
             y = old + (1.0 if self._updates == 0 else self.damping) * (y - old)
             cuts.append(self._snap(y))
         cuts.append(self.height)
-        for k in range(1, self.world):  # keep every strip at least min_rows high
-            cuts[k] = max(cuts[k], cuts[k - 1] + self.min_rows)
+        for k in range(1, self.world):  # keep every strip at least min_rows high (cuts stay in phase)
+            lo = cuts[k - 1] + self.min_rows
+            cuts[k] = max(cuts[k], lo + (self.phase - lo) % self.align)
         for k in range(self.world - 1, 0, -1):
-            cuts[k] = min(cuts[k], cuts[k + 1] - self.min_rows)
+            hi = cuts[k + 1] - self.min_rows
+            cuts[k] = min(cuts[k], hi - (hi - self.phase) % self.align)
         if all(cuts[k] < cuts[k + 1] for k in range(self.world)):
             self.bounds = [(cuts[k], cuts[k + 1]) for k in range(self.world)]
             self._updates += 1

@@ -404,8 +404,10 @@ def test_balancer_cut_points_keep_their_phase():
     rng = np.random.default_rng(7)
     for world in (2, 3, 4, 8):
         bals = [StripBalancer(1080, world, align=8, phase=7) for _ in range(2)]
-        for _ in range(20):
+        for it in range(40):
             times = [int(t) for t in rng.integers(200, 3000, world)]
+            if it % 5 == 4:  # one rank far slower than the rest: its neighbours' strips hit min_rows
+                times[int(rng.integers(0, world))] *= 400
             for b in bals:
                 b.update(times, b.bounds)
             assert bals[0].bounds == bals[1].bounds
