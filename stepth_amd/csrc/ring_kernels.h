@@ -1229,8 +1229,24 @@ __global__ __launch_bounds__(256) void gauss_vertical4_kernel(Gauss4Args a)
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const uint32_t y = i / wq, x = (i - y * wq) << 2;
         const int cl = max(0, 3 - (int)y), cr = max(0, (int)y + 3 - (int)(a.h - 1));
-        const float *w = a.wt[min(cl, 3)][min(cr, 3)];
         float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f, t3 = 0.0f;
+        if ((cl | cr) == 0) {
+            // interior rows: the one unclipped weight set, read once per wave (an index that
+            // depends on the row makes every tap a per-lane load from the argument block)
+#pragma unroll
+            for (int k = -3; k <= 3; ++k) {
+                const uint32_t v = *reinterpret_cast<const uint32_t *>(src + (size_t)((int)y + k) * a.sstride + x);
+                const float wk = a.wt[0][0][k + 3];
+                t0 = t0 + (float)(v & 255u) * wk;
+                t1 = t1 + (float)((v >> 8) & 255u) * wk;
+                t2 = t2 + (float)((v >> 16) & 255u) * wk;
+                t3 = t3 + (float)(v >> 24) * wk;
+            }
+            *reinterpret_cast<uint32_t *>(dst + (size_t)y * a.dstride + x) =
+                gauss_round(t0) | (gauss_round(t1) << 8) | (gauss_round(t2) << 16) | (gauss_round(t3) << 24);
+            continue;
+        }
+        const float *w = a.wt[min(cl, 3)][min(cr, 3)];
         for (int k = cl - 3; k <= 3 - cr; ++k) {
             const uint32_t v = *reinterpret_cast<const uint32_t *>(src + (size_t)((int)y + k) * a.sstride + x);
             const float wk = w[k + 3];
@@ -1264,6 +1280,18 @@ __global__ __launch_bounds__(256) void gauss_horizontal4_kernel(Gauss4Args a)
             b[8 + j] = (float)((d2 >> (8 * j)) & 255u);
         }
         uint32_t out = 0;
+        if (x >= 3u && x + 6u < a.w) { // all four outputs unclipped: the one interior weight set
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float t = 0.0f;
+#pragma unroll
+                for (int k = -3; k <= 3; ++k)
+                    t = t + b[4 + j + k] * a.wt[0][0][k + 3];
+                out |= gauss_round(t) << (8 * j);
+            }
+            *reinterpret_cast<uint32_t *>(dst + (size_t)y * a.dstride + x) = out;
+            continue;
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int o = (int)x + j;
