@@ -83,7 +83,7 @@ constexpr int kSadPadD = 16; // extra left apron of the R plane: the last chunk 
 // ROWS = output rows per wave: 16 costs (16+WIN-1)/16 input rows per output row, 8 costs more
 // but gives small frames twice the waves
 template <int WIN, int DC, int ROWS>
-__global__ __launch_bounds__(256) void sad_search_kernel(SadArgs a)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void sad_search_kernel(SadArgs a)
 {
     constexpr int RAD = WIN / 2;
     constexpr int kSadRows = ROWS;
@@ -108,11 +108,10 @@ __global__ __launch_bounds__(256) void sad_search_kernel(SadArgs a)
         // + k -> R(x - RAD + i - d) with k = i + (DC-1-j), d = d0 + j
         const uint32_t *rcol = a.rp + (size_t)f * a.rplane_stride + x + kSadPadD + ((int)a.d_max - 1) -
                                d0 - (DC - 1);
-        uint32_t cost[DC], run[DC], ring[WIN][DC];
+        uint32_t cost[DC], ring[WIN][DC];
 #pragma unroll
         for (int j = 0; j < DC; ++j) {
             cost[j] = 0;
-            run[j] = 0;
 #pragma unroll
             for (int s = 0; s < WIN; ++s)
                 ring[s][j] = 0;
@@ -135,14 +134,14 @@ __global__ __launch_bounds__(256) void sad_search_kernel(SadArgs a)
                         r[k] = rr[k];
 #pragma unroll
                     for (int j = 0; j < DC; ++j) {
-                        // run[j] = sum of the horizontal window sums of ALL rows so far (the sad
-                        // chain accumulates straight into it: < 2^16 per row, a strip has < 2^7
-                        // rows); ring[s][j] = its value WIN rows ago
-                        uint32_t acc = run[j];
+                        // the sad chain accumulates straight into the sum of the horizontal window
+                        // sums of ALL rows so far (< 2^16 per row, a strip has < 2^7 rows), which
+                        // is what the previous row left in its ring slot; ring[s][j] = that sum
+                        // WIN rows ago
+                        uint32_t acc = ring[(s + WIN - 1) % WIN][j];
 #pragma unroll
                         for (int i = 0; i < WIN; ++i)
                             acc = __builtin_amdgcn_sad_u8(l[i], r[i + DC - 1 - j], acc);
-                        run[j] = acc;
                         cost[j] = acc - ring[s][j];
                         ring[s][j] = acc;
                     }
