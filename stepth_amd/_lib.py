@@ -10,7 +10,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libstepth_amd.so")
+# STEPTH_AMD_LIB: another build of the same library (A/B measurements of tuning builds only)
+LIB_PATH = os.environ.get("STEPTH_AMD_LIB") or os.path.join(_HERE, "libstepth_amd.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "stepth_amd.h")
 
 ABI_VERSION = 3

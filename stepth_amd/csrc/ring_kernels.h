@@ -1115,7 +1115,9 @@ __global__ __launch_bounds__(256) void paint_list_kernel(PaintArgs a)
     if (g >= a.n_list[f])
         return;
     const GroupRec r = reinterpret_cast<const GroupRec *>(a.groups_list[f])[g];
-    if (r.y < a.row_begin || r.y >= a.row_end || r.x >= a.w)
+    // (an empty rectangle paints nothing -- like the reference's collect(); the walk below
+    // divides by the width)
+    if (r.y < a.row_begin || r.y >= a.row_end || r.x >= a.w || r.w == 0u || r.h == 0u)
         return;
     const uint8_t v = lut[a.raw[(size_t)f * a.raw_stride + g]];
     const uint32_t w = min(r.w, a.w - r.x), h = min(r.h, a.h - r.y);
