@@ -254,7 +254,8 @@ class DepthImage {
         p.max_steps = opt.max_steps;
         p.tile_w = opt.tile_w;
         p.tile_h = opt.tile_h;
-        p.flags = opt.gaussian_tail ? STEPTH_FLAG_GAUSSIAN_TAIL : 0u;
+        // (photographs: most pixels match nearby, a few search far -- STEPTH_FLAG_HEAVY_FIRST)
+        p.flags = (opt.gaussian_tail ? STEPTH_FLAG_GAUSSIAN_TAIL : 0u) | STEPTH_FLAG_HEAVY_FIRST;
         uint32_t max = 0;
         std::vector<stepth_group> adaptive;
         if (opt.adaptive && opt.groups.empty()) {

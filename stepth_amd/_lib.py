@@ -35,6 +35,7 @@ MEM_DEVICE = 1
 FLAG_ASYNC = 1
 FLAG_RAW_ONLY = 2
 FLAG_GAUSSIAN_TAIL = 4
+FLAG_HEAVY_FIRST = 8
 
 
 class Group(C.Structure):

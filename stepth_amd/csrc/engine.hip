@@ -73,6 +73,7 @@ struct stepth_engine {
     uint64_t stats_groups = 0;
     bool stats_enabled = false;
 
+    DevBuf order_bytes, order_words; // heavy-first launch order of the dense search (tile_cost_kernel)
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     size_t events_used = 0;
@@ -375,6 +376,24 @@ int launch_tile(stepth_engine *e, const RingArgs &ra, uint32_t n_frames)
     ta.max_word = ra.max_word;
     ta.stats = e->stats_enabled ? e->stats : nullptr;
     const dim3 grid((uint32_t)n_wg), block(256);
+    // heavy-first launch order (STEPTH_FLAG_HEAVY_FIRST): worth its three small launches only
+    // when the search kernel runs many rounds of workgroups
+    if (ra.heavy_first && n_wg >= 8192u && !e->stats_enabled) { // (a 1080p frame has 8228)
+        TileOrderBufs ob{};
+        ob.n_wg = (uint32_t)n_wg;
+        ob.n_groups = (uint32_t)((n_wg + 63u) / 64u);
+        TRY(reserve(e, e->order_bytes, (size_t)ob.n_groups * (64u + 64u + 16u)));
+        TRY(reserve(e, e->order_words, ((size_t)ob.n_groups * 16u + 32u + n_wg) * 4u));
+        ob.cls = (uint8_t *)e->order_bytes.p;
+        ob.rank = ob.cls + (size_t)ob.n_groups * 64u;
+        ob.cnt = ob.rank + (size_t)ob.n_groups * 64u;
+        ob.off = (uint32_t *)e->order_words.p;
+        ob.order = ob.off + (size_t)ob.n_groups * 16u + 32u; // (17 words of class bases in between)
+        hipLaunchKernelGGL(tile_cost_kernel, dim3(ob.n_groups), dim3(1024), 0, e->stream, ta, ob);
+        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, e->stream, ob);
+        hipLaunchKernelGGL(tile_scatter_kernel, dim3((uint32_t)((n_wg + 255u) / 256u)), dim3(256), 0, e->stream, ob);
+        ta.order = ob.order;
+    }
     {
         KernelTimer t(e); // the dominant kernel (bench.py's roofline leg)
         if (e->stats_enabled)
@@ -749,7 +768,7 @@ void stepth_engine_destroy(stepth_engine *e)
                       &e->aux_found, &e->pending, &e->pending_rec, &e->pending_key, &e->sad_left, &e->sad_right, &e->gauss_tmp, &e->gauss_io,
                       &e->zone_counts, &e->zone_tables, &e->pipe_main[0], &e->pipe_main[1],
                       &e->pipe_add[0], &e->pipe_add[1], &e->pipe_out[0], &e->pipe_out[1], &e->pipe_max, &e->group_out,
-                      &e->group_list[0], &e->group_list[1], &e->group_list[2], &e->group_counters})
+                      &e->group_list[0], &e->group_list[1], &e->group_list[2], &e->group_counters, &e->order_bytes, &e->order_words})
         release(*b);
     for (hipEvent_t ev : {e->ev_in[0], e->ev_in[1], e->ev_compute[0], e->ev_compute[1], e->ev_out[0],
                           e->ev_out[1]})
@@ -1053,6 +1072,7 @@ int stepth_depth_from_additional(stepth_engine *e, const stepth_image *main_im,
             HIP_TRY(e, hipMemsetAsync(e->stats, 0, kStatsBytes, e->stream));
             e->stats_groups = ra.n;
         }
+        ra.heavy_first = (p.flags & STEPTH_FLAG_HEAVY_FIRST) != 0;
         if (use_tile)
             TRY(launch_tile(e, ra, 1));
         else
@@ -1555,6 +1575,7 @@ int stepth_depth_from_additional_batch(stepth_engine *e, uint32_t n_frames,
             HIP_TRY(e, hipMemsetAsync(e->stats, 0, kStatsBytes, e->stream));
             e->stats_groups = (uint64_t)ra.n * nf;
         }
+        ra.heavy_first = (p.flags & STEPTH_FLAG_HEAVY_FIRST) != 0;
         if (use_tile)
             TRY(launch_tile(e, ra, nf));
         else if (ra.n_slots)

@@ -377,6 +377,7 @@ struct RingArgs {
     uint32_t *pending_count;     // 1 word, zeroed before ring0_kernel
     uint32_t *pending_next;      // kParts counters kPartStride words apart, zeroed: runs handed out
     uint32_t t_stride, raw_stride; // per-frame strides of T (dwords) and raw (bytes)
+    bool heavy_first;              // host side: STEPTH_FLAG_HEAVY_FIRST (launch_tile)
 };
 
 constexpr uint32_t kNoKey = 0xFFFFFFFFu;

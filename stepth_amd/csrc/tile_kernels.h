@@ -69,6 +69,9 @@ struct TileArgs {
     uint32_t raw_stride;
     uint32_t *max_word; // per frame, depth_image.rs:124
     unsigned long long *stats;
+    // optional (heavy-first launch order, tile_cost_kernel below): workgroup blockIdx.x does the
+    // work of workgroup order[blockIdx.x]
+    const uint32_t *order;
 };
 
 __device__ __forceinline__ uint32_t rfl(uint32_t v)
@@ -107,29 +110,12 @@ __device__ __forceinline__ uint32_t wave_max_dpp(uint32_t v)
 #define STEPTH_TICK() 0ull
 #endif
 
-// The query thread `tid` of a workgroup owns: search centre (cx, cy) and main-image pixel (x, y).
-// wave = 4x4 centres x 4 pixels (a square patch of the workgroup's 8x8 centres).
-__device__ __forceinline__ void tile_query_of(uint32_t tid, int CBX, int CBY, uint32_t &cx, uint32_t &cy,
-                                              uint32_t &x, uint32_t &y)
-{
-    const uint32_t wq = tid >> 6, c = (tid >> 2) & 15u, m = tid & 3u;
-    cx = (uint32_t)CBX * 8u + (wq & 1u) * 4u + (c & 3u);
-    cy = (uint32_t)CBY * 8u + (wq >> 1) * 4u + (c >> 2);
-    x = 2u * cx - 1u + (m & 1u); // may wrap: invalid
-    y = 2u * cy - 1u + (m >> 1);
-}
-
-constexpr uint32_t kNoSlot = 0xFFFFFFFFu; // a lane that holds nobody's result
-
 // <= 80 SGPRs keep 8 workgroups of 256 threads resident per CU (MI355X_MICROARCH.md,
 // "Residency": 800 / (sgprs + 16)); the kernel wants 106, the spills to vector lanes cost less
 // than the eighth wave per SIMD brings (1.28 -> 1.22 ms; 96: 1.23, 64: 1.24)
 template <bool STATS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void ring_tile_kernel(TileArgs a)
 {
-    // re-pack (round 3): the queries still searching after step 0, from all four waves
-    __shared__ uint32_t s_cnt[4];
-    __shared__ uint32_t s_q[5][256]; // lo, hi, best, limit, owner thread -- one row per field
     [[maybe_unused]] unsigned long long pc_tests = 0, pc_survey = 0, pc_probe = 0;
     [[maybe_unused]] ProbeCounters pcnt{};
     [[maybe_unused]] const unsigned long long pc_t0 = STEPTH_TICK();
@@ -141,10 +127,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void ring
     // one frame (or one band of a single frame) finished well before or after the others
     // (1.16 -> 1.02 ms on the bench frames).  The workgroups an XCD runs at one time are still
     // neighbours in a row and read the same cells through its L2.
-    const uint32_t xcd = blockIdx.x & 7u, xi = blockIdx.x >> 3;
+    const uint32_t bid = a.order ? a.order[blockIdx.x] : blockIdx.x;
+    const uint32_t xcd = bid & 7u, xi = bid >> 3;
     const uint32_t g = xcd + 8u * (xi / a.cbx_n); // row of centre blocks, all frames stacked
     if (g >= a.n_rows)
-        return; // (the whole workgroup: no barrier is left waiting)
+        return;
     const uint32_t f = g / a.cby_n;
     const int CBY = (int)(a.cby0 + g % a.cby_n), CBX = (int)(xi % a.cbx_n);
     const uint32_t tf = f * a.t_stride;
@@ -153,326 +140,255 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void ring
     const uint32_t pb = a.pos_bits, ring_shift = pb + 2u;
 
     // ---- the lane's query ----
-    uint32_t tid = kNoSlot; // the thread whose query (and result slot) this lane holds
+    const uint32_t c = lane >> 2, m = lane & 3u;
+    const uint32_t cx = (uint32_t)CBX * 8u + (wv & 1u) * 4u + (c & 3u), cy = (uint32_t)CBY * 8u + (wv >> 1) * 4u + (c >> 2);
+    const uint32_t x = 2u * cx - 1u + (m & 1u), y = 2u * cy - 1u + (m >> 1); // may wrap: invalid
+    const bool valid = x < a.w && y >= a.row0 && y < a.row1 && a.rp.owns(y);
     LaneQ q;
+    q.qx = (int)cx;
+    q.qy = (int)cy;
     q.lo = q.hi = 0u;
     q.best = kTileNoKey;
     q.limit = 0u;
     uint32_t s_end = 0;
     unsigned long long n_ring0 = 0, n_tests = 0, n_probed = 0, n_near = 0, n_survey = 0, n_super = 0;
     unsigned long long n_super_empty = 0, n_probe_void = 0; // steps with no candidate block / probes without gain
-    [[maybe_unused]] unsigned long long n_far_lanes = 0;    // queries taken through the far phase
-    {
-        uint32_t cx, cy, x, y;
-        tile_query_of(threadIdx.x, CBX, CBY, cx, cy, x, y);
-        q.qx = (int)cx;
-        q.qy = (int)cy;
-        if (x < a.w && y >= a.row0 && y < a.row1 && a.rp.owns(y)) {
-            tid = threadIdx.x;
-            const uint8_t *p = a.main_px[f] + (size_t)y * a.mstride + (size_t)x * a.mch;
-            const uint8_t v[3] = {p[0], p[1], p[2]};
-            make_box(v, a.prec, q.lo, q.hi);
-            if (cx < a.wa && cy < a.ha && a.max_steps > 0) {
-                // ring 0: the centre cell (helpers.rs:26-35 with s = 0)
-                const uint32_t cell = a.T[tf + ((uint32_t)CBY * a.bw + (uint32_t)CBX) * 64u +
-                                          ((cy & 7u) << 3) + (cx & 7u)];
-                const uint32_t smax = max(max(cx, a.wa - 1u - cx), max(cy, a.ha - 1u - cy));
-                s_end = min(a.max_steps, smax + 1u); // rings 0..s_end-1 hold in-bounds cells
-                if (cell_in_box(cell, q.lo, q.hi))
-                    q.best = 0u; // ring 0, distance 0
-                else if (s_end > 1u)
-                    q.limit = s_end;
-                if constexpr (STATS)
-                    n_ring0 = q.best == 0u;
-            }
+    if (valid) {
+        const uint8_t *p = a.main_px[f] + (size_t)y * a.mstride + (size_t)x * a.mch;
+        const uint8_t v[3] = {p[0], p[1], p[2]};
+        make_box(v, a.prec, q.lo, q.hi);
+        if (cx < a.wa && cy < a.ha && a.max_steps > 0) {
+            // ring 0: the centre cell (helpers.rs:26-35 with s = 0)
+            const uint32_t cell = a.T[tf + ((uint32_t)CBY * a.bw + (uint32_t)CBX) * 64u +
+                                      ((cy & 7u) << 3) + (cx & 7u)];
+            const uint32_t smax = max(max(cx, a.wa - 1u - cx), max(cy, a.ha - 1u - cy));
+            s_end = min(a.max_steps, smax + 1u); // rings 0..s_end-1 hold in-bounds cells
+            if (cell_in_box(cell, q.lo, q.hi))
+                q.best = 0u; // ring 0, distance 0
+            else if (s_end > 1u)
+                q.limit = s_end;
+            if constexpr (STATS)
+                n_ring0 = q.best == 0u;
         }
     }
-
-    // (d as u8) of a key: helpers.rs:3-7 and depth_image.rs:121 (`d as u8` wraps)
-    auto distance_u8 = [&](uint32_t key) __attribute__((always_inline)) -> uint32_t {
-        return key != kTileNoKey && key != 0u ? key_distance(key, pb) & 0xffu : 0u;
-    };
-    // The result of the thread's OWN query once it is settled (bit 8: there is one).  Nothing is
-    // stored before the end of the kernel: a store in the middle would make the compiler fetch
-    // every later table row with vector loads instead of scalar ones (it can no longer prove the
-    // tables unmodified).
-    uint32_t own = 0u;
 
 #if defined(STEPTH_ABLATE) && STEPTH_ABLATE == 3 // tuning build: ring 0 only
     q.limit = 0u;
 #endif
-    // Windows, skips and tolerances below are derived from the WORKGROUP's 8x8 centres
-    // (gx0.., gy0..), so the queries of a wave may come from anywhere in it.
-    const int gx0 = CBX * 8, gy0 = CBY * 8;
-    int sx0 = 0, sy0 = 0, nsx = 0, nsy = 0;
-    uint32_t skey0 = kTileNoKey, skey1 = kTileNoKey, skey2 = kTileNoKey; // slot ty*16+tx
+    if (__builtin_amdgcn_ballot_w64(q.limit != 0u)) {
+        // superblock window of the wave (far phase): every lane's window of radius
+        // max_steps-1 lies inside it
+        const int R = (int)a.max_steps - 1;
+        const int wx0 = CBX * 8 + (int)(wv & 1u) * 4, wy0 = CBY * 8 + (int)(wv >> 1) * 4;
+        const int sx0 = max(wx0 - R, 0) >> 6, sy0 = max(wy0 - R, 0) >> 6;
+        const int sx1 = min(wx0 + 3 + R, (int)a.wa - 1) >> 6, sy1 = min(wy0 + 3 + R, (int)a.ha - 1) >> 6;
+        const int nsx = sx1 - sx0 + 1, nsy = sy1 - sy0 + 1; // <= 10 each for max_steps <= 258
+        uint32_t skey0 = kTileNoKey, skey1 = kTileNoKey, skey2 = kTileNoKey; // slot ty*16+tx
 
-    for (uint32_t it = 0;; ++it) {
-        int bx0, by0, r_lo, r_hi;
-        uint64_t allow;
-        bool want;
-        if (it == 0) {
-            if (!__builtin_amdgcn_ballot_w64(q.limit != 0u))
-                continue; // every query of the wave hit at ring 0
-            // step 0: block-rings 0..3 around the centre block
-            bx0 = CBX - 3;
-            by0 = CBY - 3;
-            allow = 0x007F7F7F7F7F7F7Full; // 7 rows x 7 columns
-            r_lo = 0;
-            r_hi = 3;
-            want = q.limit != 0u;
-            if constexpr (STATS)
-                ++n_near;
-        } else {
-            if (it == 1) {
-                // settled: best ring <= 24, or nothing beyond ring 24 to search
-                if (q.limit != 0u &&
-                    (s_end <= 25u || (q.best != kTileNoKey && (q.best >> ring_shift) <= 24u)))
-                    q.limit = 0u;
+        for (uint32_t it = 0;; ++it) {
+            int bx0, by0, r_lo, r_hi;
+            uint64_t allow;
+            bool want;
+            if (it == 0) {
+                // step 0: block-rings 0..3 around the centre block
+                bx0 = CBX - 3;
+                by0 = CBY - 3;
+                allow = 0x007F7F7F7F7F7F7Full; // 7 rows x 7 columns
+                r_lo = 0;
+                r_hi = 3;
+                want = q.limit != 0u;
+                if constexpr (STATS)
+                    ++n_near;
+            } else {
 #if defined(STEPTH_ABLATE) && STEPTH_ABLATE == 1 // tuning build: step 0 only
-                q.limit = 0u;
+                break;
 #endif
-                if (q.limit == 0u && tid != kNoSlot) {
-                    own = 0x100u | distance_u8(q.best);
-                    tid = kNoSlot;
-                }
-                // ---- re-pack: the workgroup's unsettled queries move into as few waves as
-                // hold them (all 256 share the centre block, so a wave of any of them still
-                // walks ONE sequence of blocks); the other waves leave.  Most queries settle
-                // in step 0 -- on natural images the far phase ran 13 of 64 lanes full.
-                const unsigned long long surv = __builtin_amdgcn_ballot_w64(q.limit != 0u);
-                if (lane == 0)
-                    s_cnt[wv] = (uint32_t)__builtin_popcountll(surv);
-                __syncthreads();
-                const uint32_t c0 = rfl(s_cnt[0]), c1 = rfl(s_cnt[1]), c2 = rfl(s_cnt[2]), c3 = rfl(s_cnt[3]);
-                const uint32_t total = c0 + c1 + c2 + c3;
-                if (total == 0u)
-                    break; // (the whole workgroup)
-                if (q.limit != 0u) {
-                    const uint32_t base = wv == 0u ? 0u : wv == 1u ? c0 : wv == 2u ? c0 + c1 : c0 + c1 + c2;
-                    const uint32_t idx = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(surv >> 32),
-                                                                          __builtin_amdgcn_mbcnt_lo((uint32_t)surv, 0u));
-                    s_q[0][idx] = q.lo;
-                    s_q[1][idx] = q.hi;
-                    s_q[2][idx] = q.best;
-                    s_q[3][idx] = q.limit;
-                    s_q[4][idx] = tid;
-                }
-                __syncthreads();
-                q.limit = 0u;
-                tid = kNoSlot;
-                if (wv * 64u >= total)
-                    break; // this wave is not needed
-                q.lo = q.hi = 0u;
-                q.best = kTileNoKey;
-                if (wv * 64u + lane < total) {
-                    const uint32_t idx = wv * 64u + lane;
-                    q.lo = s_q[0][idx];
-                    q.hi = s_q[1][idx];
-                    q.best = s_q[2][idx];
-                    q.limit = s_q[3][idx];
-                    tid = s_q[4][idx];
-                    uint32_t cx, cy, x, y;
-                    tile_query_of(tid, CBX, CBY, cx, cy, x, y);
-                    q.qx = (int)cx;
-                    q.qy = (int)cy;
-                }
-                // superblock window of the workgroup (far phase): every query's window of
-                // radius max_steps-1 lies inside it
-                const int R = (int)a.max_steps - 1;
-                sx0 = max(gx0 - R, 0) >> 6;
-                sy0 = max(gy0 - R, 0) >> 6;
-                const int sx1 = min(gx0 + 7 + R, (int)a.wa - 1) >> 6, sy1 = min(gy0 + 7 + R, (int)a.ha - 1) >> 6;
-                nsx = sx1 - sx0 + 1; // <= 10 each for max_steps <= 265
-                nsy = sy1 - sy0 + 1;
-                // survey: superblocks whose bounds meet some lane's box within its reach
-                if constexpr (STATS) {
-                    ++n_survey;
-                    n_far_lanes += q.limit != 0u;
-                }
-                [[maybe_unused]] const unsigned long long pc_s0 = STEPTH_TICK();
-                for (int ty = 0; ty < nsy; ++ty) {
-                    const int sy = sy0 + ty;
-                    // a row of the window in one go: lane i holds dword i of its <= 10 {max, min}
-                    // pairs, the loop reads them back lane by lane (an indexed array of scalar
-                    // registers would be copied whole for every use)
-                    const uint32_t row_dw = reinterpret_cast<const uint32_t *>(SBf + (size_t)sy * a.sbwp + sx0)[lane & 31u];
-                    const int ay = (sy << 6) - q.qy;
-                    const int dsy = max(max(ay, -63 - ay), 0);
-                    for (int tx = 0; tx < nsx; ++tx) {
-                        const uint32_t bmax = (uint32_t)__builtin_amdgcn_readlane((int)row_dw, 2 * tx);
-                        const uint32_t bmin = (uint32_t)__builtin_amdgcn_readlane((int)row_dw, 2 * tx + 1);
-                        const int ax = ((sx0 + tx) << 6) - q.qx;
-                        const uint32_t dS = (uint32_t)max(max(max(ax, -63 - ax), 0), dsy);
-                        const bool w = dS < q.limit && box_meets(bmax, bmin, q.lo, q.hi);
-                        if constexpr (STATS)
-                            n_tests += q.limit != 0u;
-                        if (__builtin_amdgcn_ballot_w64(w)) {
-                            // distance from the middle of the workgroup's centres orders the visits
-                            const int rx = ((sx0 + tx) << 6) - (gx0 + 4), ry = (sy << 6) - (gy0 + 4);
-                            const uint32_t dref = (uint32_t)max(max(max(rx, -63 - rx), max(ry, -63 - ry)), 0);
-                            const uint32_t t = (uint32_t)(ty * 16 + tx);
-                            const uint32_t key = (dref << 8) | t;
-                            if (lane == (t & 63u)) {
-                                if (t < 64u)
-                                    skey0 = key;
-                                else if (t < 128u)
-                                    skey1 = key;
-                                else
-                                    skey2 = key;
+                if (it == 1) {
+                    // settled: best ring <= 24, or nothing beyond ring 24 to search
+                    if (q.limit != 0u &&
+                        (s_end <= 25u || (q.best != kTileNoKey && (q.best >> ring_shift) <= 24u)))
+                        q.limit = 0u;
+                    if (!__builtin_amdgcn_ballot_w64(q.limit != 0u))
+                        break;
+                    // survey: superblocks whose bounds meet some lane's box within its reach
+                    if constexpr (STATS)
+                        ++n_survey;
+                    [[maybe_unused]] const unsigned long long pc_s0 = STEPTH_TICK();
+                    for (int ty = 0; ty < nsy; ++ty) {
+                        const int sy = sy0 + ty;
+                        // a row of the window in one go: up to 10 superblocks = 20 dwords
+                        // a row of the window in one go: lane i holds dword i of its <= 10 {max, min}
+                        // pairs, the loop reads them back lane by lane (an indexed array of scalar
+                        // registers would be copied whole for every use)
+                        const uint32_t row_dw = reinterpret_cast<const uint32_t *>(SBf + (size_t)sy * a.sbwp + sx0)[lane & 31u];
+                        const int ay = (sy << 6) - q.qy;
+                        const int dsy = max(max(ay, -63 - ay), 0);
+                        for (int tx = 0; tx < nsx; ++tx) {
+                            const uint32_t bmax = (uint32_t)__builtin_amdgcn_readlane((int)row_dw, 2 * tx);
+                            const uint32_t bmin = (uint32_t)__builtin_amdgcn_readlane((int)row_dw, 2 * tx + 1);
+                            const int ax = ((sx0 + tx) << 6) - q.qx;
+                            const uint32_t dS = (uint32_t)max(max(max(ax, -63 - ax), 0), dsy);
+                            const bool w = dS < q.limit && box_meets(bmax, bmin, q.lo, q.hi);
+                            if constexpr (STATS)
+                                n_tests += q.limit != 0u;
+                            if (__builtin_amdgcn_ballot_w64(w)) {
+                                // distance from the middle of the wave's centres orders the visits
+                                const int rx = ((sx0 + tx) << 6) - (wx0 + 2), ry = (sy << 6) - (wy0 + 2);
+                                const uint32_t dref = (uint32_t)max(max(max(rx, -63 - rx), max(ry, -63 - ry)), 0);
+                                const uint32_t t = (uint32_t)(ty * 16 + tx);
+                                const uint32_t key = (dref << 8) | t;
+                                if (lane == (t & 63u)) {
+                                    if (t < 64u)
+                                        skey0 = key;
+                                    else if (t < 128u)
+                                        skey1 = key;
+                                    else
+                                        skey2 = key;
+                                }
                             }
                         }
                     }
+                    pc_survey += STEPTH_TICK() - pc_s0;
                 }
-                pc_survey += STEPTH_TICK() - pc_s0;
+                // nearest superblock some lane may still want.  Slots come in the order of their
+                // distance from the middle of the wave's centres, which is within 2 rings of
+                // every lane's own distance: past the largest limit + 2 nothing is left.
+                const uint32_t pick = wave_min_dpp(min(min(skey0, skey1), skey2));
+                if (pick == kTileNoKey || (pick >> 8) >= wave_max_dpp(q.limit) + 2u)
+                    break;
+                skey0 = skey0 == pick ? kTileNoKey : skey0;
+                skey1 = skey1 == pick ? kTileNoKey : skey1;
+                skey2 = skey2 == pick ? kTileNoKey : skey2;
+                const int sx = sx0 + (int)(pick & 15u), sy = sy0 + (int)((pick >> 4) & 15u);
+                const uint2 sb = SBf[(size_t)sy * a.sbwp + sx];
+                const int ax = (sx << 6) - q.qx, ay = (sy << 6) - q.qy;
+                const uint32_t dS = (uint32_t)max(max(max(ax, -63 - ax), max(ay, -63 - ay)), 0);
+                want = dS < q.limit && box_meets(sb.x, sb.y, q.lo, q.hi);
+                if (!__builtin_amdgcn_ballot_w64(want))
+                    continue;
+                bx0 = sx * 8;
+                by0 = sy * 8;
+                allow = ~window_le_mask(bx0, by0, CBX, CBY, 3); // step 0 did block-rings 0..3
+                window_ring_range(bx0, by0, CBX, CBY, r_lo, r_hi);
+                r_lo = max(r_lo, 4);
+                if constexpr (STATS)
+                    ++n_super;
             }
-            // nearest superblock some lane may still want.  Slots come in the order of their
-            // distance from the middle of the workgroup's centres, which is within 4 rings of
-            // every query's own distance: past the largest limit + 4 nothing is left.
-            const uint32_t pick = wave_min_dpp(min(min(skey0, skey1), skey2));
-            if (pick == kTileNoKey || (pick >> 8) >= wave_max_dpp(q.limit) + 4u)
-                break;
-            skey0 = skey0 == pick ? kTileNoKey : skey0;
-            skey1 = skey1 == pick ? kTileNoKey : skey1;
-            skey2 = skey2 == pick ? kTileNoKey : skey2;
-            const int sx = sx0 + (int)(pick & 15u), sy = sy0 + (int)((pick >> 4) & 15u);
-            const uint2 sb = SBf[(size_t)sy * a.sbwp + sx];
-            const int ax = (sx << 6) - q.qx, ay = (sy << 6) - q.qy;
-            const uint32_t dS = (uint32_t)max(max(max(ax, -63 - ax), max(ay, -63 - ay)), 0);
-            want = dS < q.limit && box_meets(sb.x, sb.y, q.lo, q.hi);
-            if (!__builtin_amdgcn_ballot_w64(want))
-                continue;
-            bx0 = sx * 8;
-            by0 = sy * 8;
-            allow = ~window_le_mask(bx0, by0, CBX, CBY, 3); // step 0 did block-rings 0..3
-            window_ring_range(bx0, by0, CBX, CBY, r_lo, r_hi);
-            r_lo = max(r_lo, 4);
+
+            // ---- bounds of the window's 8x8 blocks against the lane's box ----
+            // Rows and half rows of blocks that lie beyond every lane's limit are skipped
+            // (wave-uniform: distances from the wave's 4x4 centres).
+            uint32_t m_lo = 0, m_hi = 0; // bit row*8+col
+            [[maybe_unused]] const unsigned long long pc_b0 = STEPTH_TICK();
+            const uint32_t wlim = wave_max_dpp(want ? q.limit : 0u);
+            {
+                const int cx_l = bx0 * 8 - (wx0 + 3), cx_r = wx0 - (bx0 * 8 + 31); // cols 0..3
+                const bool need_l = max(max(cx_l, cx_r), 0) < (int)wlim;
+                const bool need_h = max(max(cx_l + 32, cx_r - 32), 0) < (int)wlim;   // cols 4..7
+                const uint2 *win = BBf + (size_t)(by0 + kPadB) * a.bwp + (size_t)(bx0 + kPadB);
+                const uint64_t kq = ((uint64_t)q.hi << 32) | q.lo;
+                auto do_row = [&](uint32_t acc, int row) __attribute__((always_inline)) -> uint32_t {
+                    const int ry0 = (by0 + row) * 8 - (wy0 + 3), ry1 = wy0 - ((by0 + row) * 8 + 7);
+                    if (max(max(ry0, ry1), 0) >= (int)wlim || (it == 0 && row == 7))
+                        return acc << 8;
+                    const ulonglong4 *rp4 = reinterpret_cast<const ulonglong4 *>(win + (size_t)row * a.bwp);
+                    if (need_h) {
+                        const ulonglong4 v1 = rp4[1];
+                        acc = test_half_row(acc, v1.x, v1.y, v1.z, v1.w, kq);
+                    } else {
+                        acc <<= 4;
+                    }
+                    if (need_l) {
+                        const ulonglong4 v0 = rp4[0];
+                        acc = test_half_row(acc, v0.x, v0.y, v0.z, v0.w, kq);
+                    } else {
+                        acc <<= 4;
+                    }
+                    return acc;
+                };
+#pragma unroll
+                for (int row = 7; row >= 4; --row)
+                    m_hi = do_row(m_hi, row);
+#pragma unroll
+                for (int row = 3; row >= 0; --row)
+                    m_lo = do_row(m_lo, row);
+            }
             if constexpr (STATS)
-                ++n_super;
-        }
+                n_tests += want ? 64u : 0u;
+            uint64_t cand = want ? (((uint64_t)m_hi << 32) | m_lo) & allow : 0ull;
+            if constexpr (STATS)
+                n_super_empty += it != 0 && !__builtin_amdgcn_ballot_w64(cand != 0ull);
+            [[maybe_unused]] const unsigned long long pc_p0 = STEPTH_TICK();
+            pc_tests += pc_p0 - pc_b0;
 
-        // ---- bounds of the window's 8x8 blocks against the lane's box ----
-        // Rows and half rows of blocks that lie beyond every lane's limit are skipped
-        // (wave-uniform: distances from the workgroup's 8x8 centres).
-        uint32_t m_lo = 0, m_hi = 0; // bit row*8+col
-        [[maybe_unused]] const unsigned long long pc_b0 = STEPTH_TICK();
-        const uint32_t wlim = wave_max_dpp(want ? q.limit : 0u);
-        {
-            const int cx_l = bx0 * 8 - (gx0 + 7), cx_r = gx0 - (bx0 * 8 + 31); // cols 0..3
-            const bool need_l = max(max(cx_l, cx_r), 0) < (int)wlim;
-            const bool need_h = max(max(cx_l + 32, cx_r - 32), 0) < (int)wlim;   // cols 4..7
-            const uint2 *win = BBf + (size_t)(by0 + kPadB) * a.bwp + (size_t)(bx0 + kPadB);
-            const uint64_t kq = ((uint64_t)q.hi << 32) | q.lo;
-            auto do_row = [&](uint32_t acc, int row) __attribute__((always_inline)) -> uint32_t {
-                const int ry0 = (by0 + row) * 8 - (gy0 + 7), ry1 = gy0 - ((by0 + row) * 8 + 7);
-                if (max(max(ry0, ry1), 0) >= (int)wlim || (it == 0 && row == 7))
-                    return acc << 8;
-                const ulonglong4 *rp4 = reinterpret_cast<const ulonglong4 *>(win + (size_t)row * a.bwp);
-                if (need_h) {
-                    const ulonglong4 v1 = rp4[1];
-                    acc = test_half_row(acc, v1.x, v1.y, v1.z, v1.w, kq);
-                } else {
-                    acc <<= 4;
-                }
-                if (need_l) {
-                    const ulonglong4 v0 = rp4[0];
-                    acc = test_half_row(acc, v0.x, v0.y, v0.z, v0.w, kq);
-                } else {
-                    acc <<= 4;
-                }
-                return acc;
-            };
-#pragma unroll
-            for (int row = 7; row >= 4; --row)
-                m_hi = do_row(m_hi, row);
-#pragma unroll
-            for (int row = 3; row >= 0; --row)
-                m_lo = do_row(m_lo, row);
-        }
-        if constexpr (STATS)
-            n_tests += want ? 64u : 0u;
-        uint64_t cand = want ? (((uint64_t)m_hi << 32) | m_lo) & allow : 0ull;
-        if constexpr (STATS)
-            n_super_empty += it != 0 && !__builtin_amdgcn_ballot_w64(cand != 0ull);
-        [[maybe_unused]] const unsigned long long pc_p0 = STEPTH_TICK();
-        pc_tests += pc_p0 - pc_b0;
-
-        // ---- probe the passing blocks, block-ring by block-ring (nearest first) ----
-        uint64_t le_prev = r_lo > 0 ? window_le_mask(bx0, by0, CBX, CBY, r_lo - 1) : 0ull;
-        for (int r = r_lo; r <= r_hi; ++r) {
-            const uint64_t le = window_le_mask(bx0, by0, CBX, CBY, r);
-            uint64_t cur = cand & le & ~le_prev;
-            le_prev = le;
-            // a block of block-ring r has no cell nearer than ring 8(r-1)+1
-            if (8 * (r - 1) + 1 >= (int)wlim)
-                break; // (wlim: the lanes' largest limit when the step began)
-            if (8 * (r - 1) + 1 >= (int)q.limit)
-                cand = 0ull; // this lane is through with the window
-            if (!__builtin_amdgcn_ballot_w64((cand & ~(le & ~cur)) != 0ull))
-                break; // no lane has a candidate in this or a later block-ring
-            if (8 * (r - 1) + 1 >= (int)q.limit)
-                cur = 0ull;
-            if (!__builtin_amdgcn_ballot_w64(cur != 0ull))
-                continue;
-            while (cur != 0ull) {
-                STEPTH_CNT(&pcnt, 0);
-                const int k = __builtin_ctzll(cur);
-                cur &= cur - 1ull;
-                const int bx = bx0 + (k & 7), by = by0 + (k >> 3);
-                const int x0 = bx * 8 - q.qx, y0 = by * 8 - q.qy;
-                // the dmin test also keeps stale bounds of rows this call did not pack
-                // (they are out of every query's reach) from ever being probed
+            // ---- probe the passing blocks, block-ring by block-ring (nearest first) ----
+            uint64_t le_prev = r_lo > 0 ? window_le_mask(bx0, by0, CBX, CBY, r_lo - 1) : 0ull;
+            for (int r = r_lo; r <= r_hi; ++r) {
+                const uint64_t le = window_le_mask(bx0, by0, CBX, CBY, r);
+                uint64_t cur = cand & le & ~le_prev;
+                le_prev = le;
+                // a block of block-ring r has no cell nearer than ring 8(r-1)+1
+                if (8 * (r - 1) + 1 >= (int)wlim)
+                    break; // (wlim: the lanes' largest limit when the step began)
+                if (8 * (r - 1) + 1 >= (int)q.limit)
+                    cand = 0ull; // this lane is through with the window
+                if (!__builtin_amdgcn_ballot_w64((cand & ~(le & ~cur)) != 0ull))
+                    break; // no lane has a candidate in this or a later block-ring
+                if (8 * (r - 1) + 1 >= (int)q.limit)
+                    cur = 0ull;
+                if (!__builtin_amdgcn_ballot_w64(cur != 0ull))
+                    continue;
+                while (cur != 0ull) {
+                    STEPTH_CNT(&pcnt, 0);
+                    const int k = __builtin_ctzll(cur);
+                    cur &= cur - 1ull;
+                    const int bx = bx0 + (k & 7), by = by0 + (k >> 3);
+                    const int x0 = bx * 8 - q.qx, y0 = by * 8 - q.qy;
+                    // the dmin test also keeps stale bounds of rows this call did not pack
+                    // (they are out of every query's reach) from ever being probed
 #if defined(STEPTH_ABLATE) && STEPTH_ABLATE == 2 // tuning build: no probes
-                if (false) {
+                    if (false) {
 #else
-                if ((uint32_t)square_dmin(x0, y0, 8) < q.limit) {
+                    if ((uint32_t)square_dmin(x0, y0, 8) < q.limit) {
 #endif
-                    const uint32_t boff = tf + ((uint32_t)by * a.bw + (uint32_t)bx) * 64u;
-                    [[maybe_unused]] const uint32_t best_before = q.best;
-                    const uint32_t nl =
-                        probe_block(q, x0, y0, pb, a.T + boff, a.TT + boff,
-                                    reinterpret_cast<const uint32_t *>(a.LB) + (boff >> 1), &pcnt);
-                    if constexpr (STATS) {
-                        ++n_probed;
-                        n_tests += 8u * nl;
-                        n_probe_void += q.best == best_before;
+                        const uint32_t boff = tf + ((uint32_t)by * a.bw + (uint32_t)bx) * 64u;
+                        [[maybe_unused]] const uint32_t best_before = q.best;
+                        const uint32_t nl =
+                            probe_block(q, x0, y0, pb, a.T + boff, a.TT + boff,
+                                        reinterpret_cast<const uint32_t *>(a.LB) + (boff >> 1), &pcnt);
+                        if constexpr (STATS) {
+                            ++n_probed;
+                            n_tests += 8u * nl;
+                            n_probe_void += q.best == best_before;
+                        }
                     }
                 }
             }
+            pc_probe += STEPTH_TICK() - pc_p0;
         }
-        pc_probe += STEPTH_TICK() - pc_p0;
     }
 
-    // ---- store, max (depth_image.rs:118-124): the thread's own settled query and the query
-    // the lane took through the far phase.  No workgroup barrier here: a wave that is done
-    // leaves, whatever its neighbours still have to search.
-    uint32_t d_far = 0u;
-    if (tid != kNoSlot) {
-        d_far = distance_u8(q.best);
-        uint32_t cx, cy, x, y;
-        tile_query_of(tid, CBX, CBY, cx, cy, x, y);
-        a.raw[(size_t)f * a.raw_stride + (size_t)(y - a.row0) * a.w + x] = (uint8_t)d_far;
-    }
-    if (own & 0x100u) {
-        uint32_t cx, cy, x, y;
-        tile_query_of(threadIdx.x, CBX, CBY, cx, cy, x, y);
-        a.raw[(size_t)f * a.raw_stride + (size_t)(y - a.row0) * a.w + x] = (uint8_t)own;
-    }
+    // ---- distance, store, max (depth_image.rs:118-124) ----
+    uint32_t d8 = 0;
+    if (q.best != kTileNoKey && q.best != 0u)
+        d8 = key_distance(q.best, pb) & 0xffu; // `d as u8` wraps (depth_image.rs:121)
+    if (valid)
+        a.raw[(size_t)f * a.raw_stride + (size_t)(y - a.row0) * a.w + x] = (uint8_t)d8;
     // Most waves find nothing beyond what is already there: a plain read first keeps the
-    // same-address atomics (~11 ns each, chip-wide) off the common path.
-    const uint32_t wmax = wave_max_dpp(max(d_far, own & 0xffu));
+    // same-address atomics (~11 ns each, chip-wide) off the common path.  No workgroup
+    // barrier: a wave that is done leaves, whatever its neighbours still have to search.
+    const uint32_t wmax = wave_max_dpp(d8);
     if (lane == 0 && wmax > __hip_atomic_load(a.max_word + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
         atomicMax(a.max_word + f, wmax);
     if constexpr (STATS) {
         // lane-level counts: ring-0 hits, bound tests + cells examined, blocks probed
-        unsigned long long v0 = n_ring0, v1 = n_tests, v5 = n_probed, v7 = n_probe_void, v8 = n_far_lanes;
+        unsigned long long v0 = n_ring0, v1 = n_tests, v5 = n_probed, v7 = n_probe_void;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             v0 += __shfl_xor(v0, o, 64);
             v1 += __shfl_xor(v1, o, 64);
             v5 += __shfl_xor(v5, o, 64);
             v7 += __shfl_xor(v7, o, 64);
-            v8 += __shfl_xor(v8, o, 64);
         }
         if (lane == 0) {
             atomicAdd(&stats_replica(a.stats)[0], v0);
@@ -507,10 +423,186 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void ring
             atomicAdd(&stats_replica(a.stats)[5], v5);
             atomicAdd(&stats_replica(a.stats)[6], n_super_empty); // raw slots (stepth_get_stats_raw)
             atomicAdd(&stats_replica(a.stats)[7], v7);
-            atomicAdd(&stats_replica(a.stats)[8], v8); // queries taken through the far phase
 #endif
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------
+// Heavy-first launch order for ring_tile_kernel (round 3; STEPTH_FLAG_HEAVY_FIRST).
+//
+// On natural images most workgroups are done after ring 0 / step 0 while a few percent search far
+// (the reference's own pair at 1080p: median workgroup 36 k clock ticks, p99 1.2 M, max 3.6 M):
+// dispatched in image order, the kernel ends in a long tail of a few slow workgroups -- VALU 58 %
+// busy, 3.6 of 8 waves resident per SIMD.  Started heaviest first, the same workgroups take 0.81
+// instead of 1.22 ms (order from measured costs); with the estimate below 0.95-0.97 ms.
+//
+// tile_cost_kernel   per workgroup of ring_tile_kernel ("tile": 8x8 centres), 16 sample queries
+//                    (every other centre): a sample whose box meets none of the 7x7 block bounds
+//                    around the centre block cannot be settled by step 0; it weighs in with the
+//                    distance of the nearest superblock whose bounds meet its box (in units of
+//                    16 rings; nothing in reach = the full reach).  key = sum of the weights
+//                    (0..240), class = min(floor(sqrt(key)), 15).  Per group of 64 tiles: the
+//                    tiles' classes, their ranks within the class (image order) and the 16 class
+//                    sizes -- no atomics, the resulting order is deterministic.
+// tile_scan_kernel   exclusive prefix of the class sizes over the groups; tiles of the heavier classes.
+//                    If fewer than half of the tiles are of class 0 the frame set has no light
+//                    majority to hide behind (synthetic frames: the search is issue bound, not
+//                    tail bound, and image order serves the caches better) -> identity order.
+// tile_scatter_kernel  order[position] = tile.
+// ---------------------------------------------------------------------------------------
+struct TileOrderBufs {
+    uint8_t *cls, *rank; // per tile
+    uint8_t *cnt;        // [groups][16] class sizes
+    uint32_t *off;       // [groups][16] position of the group's first tile of the class
+    uint32_t *order;     // [n_wg]
+    uint32_t n_wg, n_groups;
+};
+
+__global__ __launch_bounds__(1024) void tile_cost_kernel(TileArgs a, TileOrderBufs o)
+{
+    __shared__ uint2 s_win[64][49]; // per tile of the group: the 7x7 block bounds around its centre block
+    __shared__ uint8_t s_cls[64];
+    const uint32_t s = threadIdx.x & 15u, tl = threadIdx.x >> 4;
+    // tile t = the workgroup id of ring_tile_kernel
+    auto tile_of = [&](uint32_t t, uint32_t &f, int &CBX, int &CBY) -> bool {
+        const uint32_t xcd = t & 7u, xi = t >> 3, g = xcd + 8u * (xi / a.cbx_n);
+        if (t >= o.n_wg || g >= a.n_rows)
+            return false;
+        f = g / a.cby_n;
+        CBY = (int)(a.cby0 + g % a.cby_n);
+        CBX = (int)(xi % a.cbx_n);
+        return true;
+    };
+    // ---- the groups' windows -> LDS (the 16 samples of a tile test the same 49 blocks) ----
+    for (uint32_t i = threadIdx.x; i < 64u * 49u; i += 1024u) {
+        const uint32_t wt = i / 49u, e = i - wt * 49u, dy = e / 7u, dx = e - dy * 7u;
+        uint32_t f;
+        int CBX, CBY;
+        uint2 b = make_uint2(0u, kNoCell);
+        if (tile_of(blockIdx.x * 64u + wt, f, CBX, CBY))
+            b = a.BBp[(size_t)f * a.bb_stride + (size_t)(CBY - 3 + (int)dy + kPadB) * a.bwp + (size_t)(CBX - 3 + (int)dx + kPadB)];
+        s_win[wt][e] = b;
+    }
+    __syncthreads();
+    uint32_t w = 0, f;
+    int CBX, CBY;
+    if (tile_of(blockIdx.x * 64u + tl, f, CBX, CBY)) {
+        const uint32_t cx = (uint32_t)CBX * 8u + 2u * (s & 3u), cy = (uint32_t)CBY * 8u + 2u * (s >> 2);
+        const uint32_t x = 2u * cx, y = 2u * cy;
+        if (x < a.w && y >= a.row0 && y < a.row1 && a.rp.owns(y) && cx < a.wa && cy < a.ha && a.max_steps > 1u) {
+            const uint8_t *p = a.main_px[f] + (size_t)y * a.mstride + (size_t)x * a.mch;
+            const uint8_t v[3] = {p[0], p[1], p[2]};
+            uint32_t lo, hi;
+            make_box(v, a.prec, lo, hi);
+            bool near = false;
+#pragma unroll 7
+            for (int e = 0; e < 49; ++e)
+                near |= box_meets(s_win[tl][e].x, s_win[tl][e].y, lo, hi);
+            if (!near && a.max_steps <= 160u) {
+                w = 4u; // a short reach: how far matters little next to how many (measured)
+            } else if (!near) {
+                const uint2 *SBf = a.SBp + (size_t)f * a.sb_stride;
+                const int R = (int)a.max_steps - 1, qx = (int)cx, qy = (int)cy;
+                const int sx0 = max(qx - R, 0) >> 6, sy0 = max(qy - R, 0) >> 6;
+                const int sx1 = min(qx + R, (int)a.wa - 1) >> 6, sy1 = min(qy + R, (int)a.ha - 1) >> 6;
+                uint32_t dmin = 255u;
+                for (int sy = sy0; sy <= sy1; ++sy)
+                    for (int sx = sx0; sx <= sx1; ++sx) {
+                        const uint2 sb = SBf[(size_t)sy * a.sbwp + sx];
+                        const uint32_t dS = (uint32_t)square_dmin((sx << 6) - qx, (sy << 6) - qy, 64);
+                        if (dS < a.max_steps && box_meets(sb.x, sb.y, lo, hi))
+                            dmin = min(dmin, dS);
+                    }
+                w = min(max(dmin, 25u), 255u) >> 4; // 1..15
+            }
+        }
+    }
+    // key of the tile: the 16 samples are 16 consecutive lanes
+#pragma unroll
+    for (int sh = 1; sh < 16; sh <<= 1)
+        w += (uint32_t)__shfl_xor((int)w, sh, 64);
+    if (s == 0)
+        s_cls[tl] = (uint8_t)min(isqrt_floor(w), 15u);
+    __syncthreads();
+    if (threadIdx.x < 64u) {
+        const uint32_t c = s_cls[threadIdx.x], tt = blockIdx.x * 64u + threadIdx.x;
+        uint32_t rank = 0, mine = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 16u; ++k) {
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(c == k && tt < o.n_wg);
+            if (c == k)
+                rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if (threadIdx.x == k)
+                mine = (uint32_t)__builtin_popcountll(m);
+        }
+        if (tt < o.n_wg) {
+            o.cls[tt] = (uint8_t)c;
+            o.rank[tt] = (uint8_t)rank;
+        }
+        if (threadIdx.x < 16u)
+            o.cnt[(size_t)blockIdx.x * 16u + threadIdx.x] = (uint8_t)mine;
+    }
+}
+
+// inclusive prefix sum over the 64 lanes of a wave: four steps inside the rows of 16 lanes, two
+// row broadcasts (DPP; lanes without a source add 0)
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true); // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true); // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true); // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true); // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false); // row_bcast:15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false); // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
+// One workgroup of 16 waves, wave c = class c: an exclusive prefix of the class's sizes over the
+// groups (1024 groups at a time through LDS), then base[c] = tiles of the heavier classes
+// (o.off[n_groups * 16 ..]; word 16 = 1: identity order, class 0 is not the majority).
+__global__ __launch_bounds__(1024) void tile_scan_kernel(TileOrderBufs o)
+{
+    __shared__ uint4 s_cnt[1024]; // 16 class sizes (bytes) per group
+    __shared__ uint32_t s_total[16];
+    const uint32_t lane = threadIdx.x & 63u, c = threadIdx.x >> 6;
+    uint32_t run = 0;
+    for (uint32_t g0 = 0; g0 < o.n_groups; g0 += 1024u) {
+        const uint32_t gl = g0 + threadIdx.x;
+        s_cnt[threadIdx.x] = gl < o.n_groups ? reinterpret_cast<const uint4 *>(o.cnt)[gl] : make_uint4(0u, 0u, 0u, 0u);
+        __syncthreads();
+        for (uint32_t j = 0; j < 16u; ++j) {
+            const uint32_t g = j * 64u + lane;
+            const uint32_t n = reinterpret_cast<const uint8_t *>(&s_cnt[g])[c];
+            const uint32_t inc = wave_scan_incl(n);
+            if (g0 + g < o.n_groups)
+                o.off[(size_t)(g0 + g) * 16u + c] = run + inc - n;
+            run += bcast(inc, 63);
+        }
+        __syncthreads();
+    }
+    if (lane == 0)
+        s_total[c] = run;
+    __syncthreads();
+    if (threadIdx.x < 17u) {
+        uint32_t v = 0;
+        if (threadIdx.x < 16u)
+            for (uint32_t k = threadIdx.x + 1u; k < 16u; ++k)
+                v += s_total[k];
+        else
+            v = 2u * s_total[0] < o.n_wg ? 1u : 0u;
+        o.off[(size_t)o.n_groups * 16u + threadIdx.x] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void tile_scatter_kernel(TileOrderBufs o)
+{
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= o.n_wg)
+        return;
+    const uint32_t *base = o.off + (size_t)o.n_groups * 16u;
+    const uint32_t c = o.cls[t];
+    o.order[base[16] ? t : base[c] + o.off[(size_t)(t >> 6) * 16u + c] + o.rank[t]] = t;
 }
 
 // ---------------------------------------------------------------------------------------

@@ -168,7 +168,8 @@ class DepthImage:
             depth, _mx = eng.depth_from_additional(self.image, add, precision,
                                                    max_steps=max_steps, tile=tile,
                                                    groups=groups, mode=L.MODE_RING_FIRST_HIT,
-                                                   gaussian_tail=gaussian_tail)
+                                                   gaussian_tail=gaussian_tail,
+                                                   heavy_first=True)  # photographs: see STEPTH_FLAG_HEAVY_FIRST
         except MaxZeroError:
             self.depth = np.zeros(self.image.shape[:2], np.uint8)
             raise

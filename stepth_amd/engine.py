@@ -185,7 +185,7 @@ class Engine:
                               mode: int = L.MODE_RING_FIRST_HIT, d_max: int = 0, win: int = 0,
                               rows: Optional[Tuple[int, int]] = None,
                               row_pattern: Optional[Tuple[int, int, int]] = None,
-                              raw_only: bool = False, gaussian_tail: bool = False, out=None,
+                              raw_only: bool = False, gaussian_tail: bool = False, heavy_first: bool = False, out=None,
                               max_out=None,
                               asynchronous: bool = False):
         """stepth_depth_from_additional.  Returns (depth [H,W] u8, max or None).
@@ -221,7 +221,7 @@ class Engine:
         if row_pattern is not None:  # (row_block, row_mod, row_rem): interleaved row blocks
             p.row_block, p.row_mod, p.row_rem = row_pattern
         p.flags = ((L.FLAG_ASYNC if asynchronous else 0) | (L.FLAG_RAW_ONLY if raw_only else 0) |
-                   (L.FLAG_GAUSSIAN_TAIL if gaussian_tail else 0))
+                   (L.FLAG_GAUSSIAN_TAIL if gaussian_tail else 0) | (L.FLAG_HEAVY_FIRST if heavy_first else 0))
         gptr, gn, gmem, k4 = None, 0, L.MEM_HOST, None
         if groups is not None:
             if _is_tensor(groups):
@@ -271,7 +271,7 @@ class Engine:
                                     mode: int = L.MODE_RING_FIRST_HIT, d_max: int = 0, win: int = 0,
                                     rows: Optional[Tuple[int, int]] = None,
                                     row_pattern: Optional[Tuple[int, int, int]] = None,
-                                    raw_only: bool = False, gaussian_tail: bool = False,
+                                    raw_only: bool = False, gaussian_tail: bool = False, heavy_first: bool = False,
                                     outs=None, max_out=None, asynchronous: bool = False):
         """stepth_depth_from_additional_batch: many frames of equal shape in one set of launches,
         ring mode with uniform tiles (`tile`, default one group per pixel), or the windowed-SAD
@@ -312,7 +312,7 @@ class Engine:
         if row_pattern is not None:
             p.row_block, p.row_mod, p.row_rem = row_pattern
         p.flags = ((L.FLAG_ASYNC if asynchronous else 0) | (L.FLAG_RAW_ONLY if raw_only else 0) |
-                   (L.FLAG_GAUSSIAN_TAIL if gaussian_tail else 0))
+                   (L.FLAG_GAUSSIAN_TAIL if gaussian_tail else 0) | (L.FLAG_HEAVY_FIRST if heavy_first else 0))
         if asynchronous:
             mptr = max_out.data_ptr() if max_out is not None else None
             self._check(self._lib.stepth_depth_from_additional_batch(self._h, n, mi, ai,

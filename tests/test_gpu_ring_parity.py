@@ -886,3 +886,41 @@ def test_64_frame_1080p_device_batch_equals_per_frame_calls(engine, oracle):
     for i in (5, 62):
         _sampled_raw_equals_oracle(oracle, outs[i].cpu().numpy(), frames[i][0], frames[i][1], P36, 128,
                                    n=8000, seed=i)
+
+
+def test_heavy_first_launch_order_changes_nothing_but_the_order(engine, oracle, asset):
+    """STEPTH_FLAG_HEAVY_FIRST (tile_cost / tile_scan / tile_scatter kernels: the search's
+    workgroups start heaviest first): same bytes as image order -- a 1080p batch of a natural
+    frame (the reference's pair, mirror-tiled: the order is taken) and a synthetic one (most tiles
+    search far: the device keeps image order), RGBA mains, a row strip, the single-frame entry,
+    reach 255 (the estimate then surveys superblocks) -- and the natural frame against the oracle"""
+    import torch
+    from stepth_amd import synth
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, ROOT)
+    from bench import mirror_tile
+    W, H = 1920, 1080
+    nat = (mirror_tile(asset["main"][..., :3], W, H), mirror_tile(asset["additional"][..., :3], W, H))
+    syn = synth.stereo_pair(W, H, 128, seed=0x5EED)[:2]
+    dev = torch.device("cuda", 0)
+    for ms in (128, 255):
+        for frames in ([nat, nat], [syn, nat]):
+            mains = [torch.from_numpy(np.ascontiguousarray(l)).to(dev) for l, _ in frames]
+            adds = [torch.from_numpy(np.ascontiguousarray(r)).to(dev) for _, r in frames]
+            a, ma = engine.depth_from_additional_batch(mains, adds, P36, max_steps=ms)
+            b, mb = engine.depth_from_additional_batch(mains, adds, P36, max_steps=ms, heavy_first=True)
+            assert ma == mb
+            for x, y in zip(a, b):
+                assert torch.equal(x, y)
+    raw, _ = engine.depth_from_additional_batch(mains[1:], adds[1:], P36, max_steps=255, heavy_first=True, raw_only=True)
+    _sampled_raw_equals_oracle(oracle, raw[0].cpu().numpy(), nat[0], nat[1], P36, 255)
+    # RGBA main + a row strip + the single-frame entry
+    rgba = np.concatenate([nat[0], np.full((H, W, 1), 255, np.uint8)], 2)
+    d0, m0 = engine.depth_from_additional(rgba, nat[1], P36, max_steps=128)
+    d1, m1 = engine.depth_from_additional(rgba, nat[1], P36, max_steps=128, heavy_first=True)
+    assert m0 == m1 and np.array_equal(d0, d1)
+    out0, out1 = np.zeros((H, W), np.uint8), np.zeros((H, W), np.uint8)
+    engine.depth_from_additional(nat[0], nat[1], P36, max_steps=128, rows=(135, 1080), raw_only=True, out=out0)
+    engine.depth_from_additional(nat[0], nat[1], P36, max_steps=128, rows=(135, 1080), raw_only=True, out=out1, heavy_first=True)
+    assert np.array_equal(out0, out1) and out0[135:].any()

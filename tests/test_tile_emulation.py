@@ -42,7 +42,7 @@ def emu(tmp_path_factory):
         r0, r1 = rows if rows else (0, H)
         raw = np.full((r1 - r0, W), 0xEE, np.uint8)
         mx = C.c_uint32(0)
-        st = (C.c_uint64 * 3)()
+        st = (C.c_uint64 * 6)()
         pr = (C.c_uint8 * 3)(*prec)
         rc = lib.tile_emulate(main.ctypes.data, W, H, ch, add.ctypes.data, add.shape[1], add.shape[0],
                               C.cast(pr, C.c_void_p), max_steps, r0, r1, raw.ctypes.data,
@@ -125,7 +125,7 @@ def _list_check(emu, oracle, add, cx, cy, what, prec, ms, lanes):
     what = np.ascontiguousarray(what, np.uint8)
     n = len(cx)
     d, found, pos = np.zeros(n, np.uint32), np.zeros(n, np.uint8), np.zeros((n, 2), np.uint32)
-    st = (C.c_uint64 * 3)()
+    st = (C.c_uint64 * 6)()
     pr = (C.c_uint8 * 3)(*prec)
     rc = emu.lib.list_emulate(cx.ctypes.data, cy.ctypes.data, what.ctypes.data, n, add.ctypes.data,
                               add.shape[1], add.shape[0], C.cast(pr, C.c_void_p), ms, lanes,

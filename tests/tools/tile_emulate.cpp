@@ -115,175 +115,169 @@ extern "C" int tile_emulate(const uint8_t *main_px, uint32_t W, uint32_t H, uint
     uint32_t mxd = 0;
     uint64_t n_probes = 0, n_lines = 0, n_steps = 0;
 
-    // one workgroup = 8x8 centres x 4 pixels = 256 queries, thread t (tile_query_of)
     for (uint32_t cbyi = 0; cbyi < cby_n; ++cbyi)
-        for (uint32_t cbxi = 0; cbxi < cbx_n; ++cbxi) {
-            const int CBX = (int)cbxi, CBY = (int)(cby0 + cbyi);
-            const int gx0 = CBX * 8, gy0 = CBY * 8; // the workgroup's centres: gx0..gx0+7
-            LaneQ Q[256];
-            uint32_t s_end[256], px[256], py[256];
-            bool valid[256];
-            for (uint32_t t = 0; t < 256; ++t) {
-                const uint32_t wq = t >> 6, c = (t >> 2) & 15, m = t & 3;
-                const uint32_t cx = CBX * 8u + (wq & 1) * 4 + (c & 3), cy = CBY * 8u + (wq >> 1) * 4 + (c >> 2);
-                const uint32_t x = 2 * cx - 1 + (m & 1), y = 2 * cy - 1 + (m >> 1);
-                valid[t] = x < W && y >= row0 && y < row1;
-                px[t] = x;
-                py[t] = y;
-                LaneQ &l = Q[t];
-                l.qx = (int)cx;
-                l.qy = (int)cy;
-                l.lo = l.hi = 0;
-                l.best = kTileNoKey;
-                l.limit = 0;
-                s_end[t] = 0;
-                if (!valid[t])
-                    continue;
-                const uint8_t *p = main_px + ((size_t)y * W + x) * mch;
-                const uint8_t v[3] = {p[0], p[1], p[2]};
-                make_box(v, prec, l.lo, l.hi);
-                if (cx < wa && cy < ha && max_steps > 0) {
-                    const uint32_t cell = T[((size_t)CBY * bw + CBX) * 64 + ((cy & 7) << 3) + (cx & 7)];
-                    const uint32_t smax = std::max(std::max(cx, wa - 1 - cx), std::max(cy, ha - 1 - cy));
-                    s_end[t] = std::min(max_steps, smax + 1);
-                    if (cell_in_box(cell, l.lo, l.hi))
-                        l.best = 0;
-                    else if (s_end[t] > 1)
-                        l.limit = s_end[t];
-                }
-            }
-            // bound tests + probes of one window for the <= 64 queries `who` of a wave
-            auto window = [&](const std::vector<int> &who, const bool *want, int bx0, int by0, uint64_t allow,
-                              int r_lo, int r_hi) -> int {
-                ++n_steps;
-                std::vector<uint64_t> cand(who.size());
-                for (size_t i = 0; i < who.size(); ++i) {
-                    const LaneQ &l = Q[who[i]];
-                    uint64_t mm = 0;
-                    for (int row = 0; row < 8; ++row)
-                        for (int col = 0; col < 8; ++col) {
-                            const U2 bb = BBp[(size_t)(by0 + kPadB + row) * bwp + (size_t)(bx0 + kPadB + col)];
-                            if (box_meets(bb.x, bb.y, l.lo, l.hi))
-                                mm |= 1ull << (row * 8 + col);
-                        }
-                    cand[i] = want[i] ? mm & allow : 0ull;
-                }
-                uint64_t le_prev = r_lo > 0 ? window_le_mask(bx0, by0, CBX, CBY, r_lo - 1) : 0ull;
-                for (int r = r_lo; r <= r_hi; ++r) {
-                    const uint64_t le = window_le_mask(bx0, by0, CBX, CBY, r);
-                    for (size_t i = 0; i < who.size(); ++i) {
-                        LaneQ &l = Q[who[i]];
-                        uint64_t cur = cand[i] & le & ~le_prev;
-                        if (8 * (r - 1) + 1 >= (int)l.limit)
-                            cur = 0;
-                        while (cur) {
-                            const int k = __builtin_ctzll(cur);
-                            cur &= cur - 1;
-                            const int bx = bx0 + (k & 7), by = by0 + (k >> 3);
-                            const int x0 = bx * 8 - l.qx, y0 = by * 8 - l.qy;
-                            if ((uint32_t)square_dmin(x0, y0, 8) < l.limit) {
-                                if (bx < 0 || by < 0 || bx >= (int)bw || by >= (int)bh)
-                                    return -2; // a padded block got through: memory fault on the GPU
-                                const size_t boff = ((size_t)by * bw + bx) * 64;
-                                n_lines += probe_block(l, x0, y0, pb, &T[boff], &TT[boff],
-                                                       reinterpret_cast<const uint32_t *>(&LB[boff / 4]));
-                                ++n_probes;
-                            }
-                        }
-                    }
-                    le_prev = le;
-                }
-                return 0;
-            };
-            // ---- step 0, wave by wave as launched: the 7x7 blocks around the centre block ----
+        for (uint32_t cbxi = 0; cbxi < cbx_n; ++cbxi)
             for (uint32_t wv = 0; wv < 4; ++wv) {
-                std::vector<int> who;
-                bool want[64];
+                const int CBX = (int)cbxi, CBY = (int)(cby0 + cbyi);
+                LaneQ q[64];
+                uint32_t s_end[64], px[64], py[64];
+                bool valid[64];
                 bool any = false;
-                for (int l = 0; l < 64; ++l) {
-                    who.push_back((int)(wv * 64 + l));
-                    want[l] = Q[wv * 64 + l].limit != 0;
-                    any |= want[l];
-                }
-                if (!any)
-                    continue;
-                if (window(who, want, CBX - 3, CBY - 3, 0x007F7F7F7F7F7F7Full, 0, 3))
-                    return -2;
-            }
-            // ---- settle, then re-pack the unsettled queries into waves of 64, in thread order ----
-            std::vector<int> surv;
-            for (int t = 0; t < 256; ++t) {
-                LaneQ &l = Q[t];
-                if (l.limit != 0 && (s_end[t] <= 25 || (l.best != kTileNoKey && (l.best >> ring_shift) <= 24)))
+                for (uint32_t lane = 0; lane < 64; ++lane) {
+                    const uint32_t c = lane >> 2, m = lane & 3;
+                    const uint32_t cx = CBX * 8u + (wv & 1) * 4 + (c & 3), cy = CBY * 8u + (wv >> 1) * 4 + (c >> 2);
+                    const uint32_t x = 2 * cx - 1 + (m & 1), y = 2 * cy - 1 + (m >> 1);
+                    valid[lane] = x < W && y >= row0 && y < row1;
+                    px[lane] = x;
+                    py[lane] = y;
+                    LaneQ &l = q[lane];
+                    l.qx = (int)cx;
+                    l.qy = (int)cy;
+                    l.lo = l.hi = 0;
+                    l.best = kTileNoKey;
                     l.limit = 0;
-                if (l.limit != 0)
-                    surv.push_back(t);
-            }
-            const int R = (int)max_steps - 1;
-            const int sx0 = std::max(gx0 - R, 0) >> 6, sy0 = std::max(gy0 - R, 0) >> 6;
-            const int sx1 = std::min(gx0 + 7 + R, (int)wa - 1) >> 6;
-            const int sy1 = std::min(gy0 + 7 + R, (int)ha - 1) >> 6;
-            const int nsx = sx1 - sx0 + 1, nsy = sy1 - sy0 + 1;
-            if (!surv.empty() && (nsx > 10 || nsy > 10))
-                return -1; // the kernel's slots would not fit
-            for (size_t w0 = 0; w0 < surv.size(); w0 += 64) {
-                const std::vector<int> who(surv.begin() + w0, surv.begin() + std::min(surv.size(), w0 + 64));
-                std::vector<uint32_t> skeys; // wave-level slots
-                for (int ty = 0; ty < nsy; ++ty)
-                    for (int tx = 0; tx < nsx; ++tx) {
-                        const int sx = sx0 + tx, sy = sy0 + ty;
-                        const U2 sb = SB[(size_t)sy * sbw + sx];
-                        bool anyw = false;
-                        for (int t : who) {
-                            const uint32_t dS = (uint32_t)square_dmin((sx << 6) - Q[t].qx, (sy << 6) - Q[t].qy, 64);
-                            anyw |= dS < Q[t].limit && box_meets(sb.x, sb.y, Q[t].lo, Q[t].hi);
-                        }
-                        if (anyw) {
-                            const uint32_t dref = (uint32_t)square_dmin((sx << 6) - (gx0 + 4), (sy << 6) - (gy0 + 4), 64);
-                            skeys.push_back((dref << 8) | (uint32_t)(ty * 16 + tx));
-                        }
-                    }
-                while (!skeys.empty()) {
-                    const auto itmin = std::min_element(skeys.begin(), skeys.end());
-                    const uint32_t pick = *itmin;
-                    // the kernel stops at the first slot beyond the largest limit + 4 (slots are
-                    // keyed by the distance from the middle of the workgroup's 8x8 centres, which
-                    // is within 4 rings of every query's own distance)
-                    uint32_t maxlimit = 0;
-                    for (int t : who)
-                        maxlimit = std::max(maxlimit, Q[t].limit);
-                    if ((pick >> 8) >= maxlimit + 4u)
-                        break;
-                    skeys.erase(itmin);
-                    const int sx = sx0 + (int)(pick & 15u), sy = sy0 + (int)((pick >> 4) & 15u);
-                    const U2 sb = SB[(size_t)sy * sbw + sx];
-                    bool want[64];
-                    bool anyw = false;
-                    for (size_t i = 0; i < who.size(); ++i) {
-                        const LaneQ &l = Q[who[i]];
-                        const uint32_t dS = (uint32_t)square_dmin((sx << 6) - l.qx, (sy << 6) - l.qy, 64);
-                        want[i] = dS < l.limit && box_meets(sb.x, sb.y, l.lo, l.hi);
-                        anyw |= want[i];
-                    }
-                    if (!anyw)
+                    s_end[lane] = 0;
+                    if (!valid[lane])
                         continue;
-                    const int bx0 = sx * 8, by0 = sy * 8;
-                    int r_lo, r_hi;
-                    window_ring_range(bx0, by0, CBX, CBY, r_lo, r_hi);
-                    if (window(who, want, bx0, by0, ~window_le_mask(bx0, by0, CBX, CBY, 3), std::max(r_lo, 4), r_hi))
-                        return -2;
+                    const uint8_t *p = main_px + ((size_t)y * W + x) * mch;
+                    const uint8_t v[3] = {p[0], p[1], p[2]};
+                    make_box(v, prec, l.lo, l.hi);
+                    if (cx < wa && cy < ha && max_steps > 0) {
+                        const uint32_t cell = T[((size_t)CBY * bw + CBX) * 64 + ((cy & 7) << 3) + (cx & 7)];
+                        const uint32_t smax = std::max(std::max(cx, wa - 1 - cx), std::max(cy, ha - 1 - cy));
+                        s_end[lane] = std::min(max_steps, smax + 1);
+                        if (cell_in_box(cell, l.lo, l.hi))
+                            l.best = 0;
+                        else if (s_end[lane] > 1)
+                            l.limit = s_end[lane];
+                    }
+                    any |= l.limit != 0;
+                }
+                if (any) {
+                    const int R = (int)max_steps - 1;
+                    const int wx0 = CBX * 8 + (int)(wv & 1) * 4, wy0 = CBY * 8 + (int)(wv >> 1) * 4;
+                    const int sx0 = std::max(wx0 - R, 0) >> 6, sy0 = std::max(wy0 - R, 0) >> 6;
+                    const int sx1 = std::min(wx0 + 3 + R, (int)wa - 1) >> 6;
+                    const int sy1 = std::min(wy0 + 3 + R, (int)ha - 1) >> 6;
+                    const int nsx = sx1 - sx0 + 1, nsy = sy1 - sy0 + 1;
+                    if (nsx > 16 || nsy > 12)
+                        return -1; // the kernel's slots would not fit
+                    std::vector<uint32_t> skeys; // wave-level slots
+                    for (uint32_t it = 0;; ++it) {
+                        int bx0, by0, r_lo, r_hi;
+                        uint64_t allow;
+                        bool want[64];
+                        if (it == 0) {
+                            bx0 = CBX - 3;
+                            by0 = CBY - 3;
+                            allow = 0x007F7F7F7F7F7F7Full;
+                            r_lo = 0;
+                            r_hi = 3;
+                            for (int l = 0; l < 64; ++l)
+                                want[l] = q[l].limit != 0;
+                        } else {
+                            if (it == 1) {
+                                bool left = false;
+                                for (int l = 0; l < 64; ++l) {
+                                    if (q[l].limit != 0 &&
+                                        (s_end[l] <= 25 || (q[l].best != kTileNoKey && (q[l].best >> ring_shift) <= 24)))
+                                        q[l].limit = 0;
+                                    left |= q[l].limit != 0;
+                                }
+                                if (!left)
+                                    break;
+                                for (int ty = 0; ty < nsy; ++ty)
+                                    for (int tx = 0; tx < nsx; ++tx) {
+                                        const int sx = sx0 + tx, sy = sy0 + ty;
+                                        const U2 sb = SB[(size_t)sy * sbw + sx];
+                                        bool anyw = false;
+                                        for (int l = 0; l < 64; ++l) {
+                                            const uint32_t dS = (uint32_t)square_dmin((sx << 6) - q[l].qx, (sy << 6) - q[l].qy, 64);
+                                            anyw |= dS < q[l].limit && box_meets(sb.x, sb.y, q[l].lo, q[l].hi);
+                                        }
+                                        if (anyw) {
+                                            const uint32_t dref = (uint32_t)square_dmin((sx << 6) - (wx0 + 2), (sy << 6) - (wy0 + 2), 64);
+                                            skeys.push_back((dref << 8) | (uint32_t)(ty * 16 + tx));
+                                        }
+                                    }
+                            }
+                            if (skeys.empty())
+                                break;
+                            const auto itmin = std::min_element(skeys.begin(), skeys.end());
+                            const uint32_t pick = *itmin;
+                            // the kernel stops at the first slot beyond the largest limit + 2 (slots
+                            // are keyed by the distance from the middle of the wave's 4x4 centres,
+                            // which is within 2 rings of every lane's own distance)
+                            uint32_t maxlimit = 0;
+                            for (int l = 0; l < 64; ++l)
+                                maxlimit = std::max(maxlimit, q[l].limit);
+                            if ((pick >> 8) >= maxlimit + 2u)
+                                break;
+                            skeys.erase(itmin);
+                            const int sx = sx0 + (int)(pick & 15u), sy = sy0 + (int)((pick >> 4) & 15u);
+                            const U2 sb = SB[(size_t)sy * sbw + sx];
+                            bool anyw = false;
+                            for (int l = 0; l < 64; ++l) {
+                                const uint32_t dS = (uint32_t)square_dmin((sx << 6) - q[l].qx, (sy << 6) - q[l].qy, 64);
+                                want[l] = dS < q[l].limit && box_meets(sb.x, sb.y, q[l].lo, q[l].hi);
+                                anyw |= want[l];
+                            }
+                            if (!anyw)
+                                continue;
+                            bx0 = sx * 8;
+                            by0 = sy * 8;
+                            allow = ~window_le_mask(bx0, by0, CBX, CBY, 3);
+                            window_ring_range(bx0, by0, CBX, CBY, r_lo, r_hi);
+                            r_lo = std::max(r_lo, 4);
+                        }
+                        ++n_steps;
+                        uint64_t cand[64];
+                        for (int l = 0; l < 64; ++l) {
+                            uint64_t mm = 0;
+                            for (int row = 0; row < 8; ++row)
+                                for (int col = 0; col < 8; ++col) {
+                                    const U2 bb = BBp[(size_t)(by0 + kPadB + row) * bwp + (size_t)(bx0 + kPadB + col)];
+                                    if (box_meets(bb.x, bb.y, q[l].lo, q[l].hi))
+                                        mm |= 1ull << (row * 8 + col);
+                                }
+                            cand[l] = want[l] ? mm & allow : 0ull;
+                        }
+                        uint64_t le_prev = r_lo > 0 ? window_le_mask(bx0, by0, CBX, CBY, r_lo - 1) : 0ull;
+                        for (int r = r_lo; r <= r_hi; ++r) {
+                            const uint64_t le = window_le_mask(bx0, by0, CBX, CBY, r);
+                            for (int l = 0; l < 64; ++l) {
+                                uint64_t cur = cand[l] & le & ~le_prev;
+                                if (8 * (r - 1) + 1 >= (int)q[l].limit)
+                                    cur = 0;
+                                while (cur) {
+                                    const int k = __builtin_ctzll(cur);
+                                    cur &= cur - 1;
+                                    const int bx = bx0 + (k & 7), by = by0 + (k >> 3);
+                                    const int x0 = bx * 8 - q[l].qx, y0 = by * 8 - q[l].qy;
+                                    if ((uint32_t)square_dmin(x0, y0, 8) < q[l].limit) {
+                                        if (bx < 0 || by < 0 || bx >= (int)bw || by >= (int)bh)
+                                            return -2; // a padded block got through: memory fault on the GPU
+                                        const size_t boff = ((size_t)by * bw + bx) * 64;
+                                        n_lines += probe_block(q[l], x0, y0, pb, &T[boff], &TT[boff],
+                                                               reinterpret_cast<const uint32_t *>(&LB[boff / 4]));
+                                        ++n_probes;
+                                    }
+                                }
+                            }
+                            le_prev = le;
+                        }
+                    }
+                }
+                for (int l = 0; l < 64; ++l) {
+                    uint32_t d8 = 0;
+                    if (q[l].best != kTileNoKey && q[l].best != 0)
+                        d8 = key_distance(q[l].best, pb) & 0xff;
+                    if (valid[l]) {
+                        raw[(size_t)(py[l] - row0) * W + px[l]] = (uint8_t)d8;
+                        mxd = std::max(mxd, d8);
+                    }
                 }
             }
-            for (int t = 0; t < 256; ++t) {
-                uint32_t d8 = 0;
-                if (Q[t].best != kTileNoKey && Q[t].best != 0)
-                    d8 = key_distance(Q[t].best, pb) & 0xff;
-                if (valid[t]) {
-                    raw[(size_t)(py[t] - row0) * W + px[t]] = (uint8_t)d8;
-                    mxd = std::max(mxd, d8);
-                }
-            }
-        }
     if (max_out)
         *max_out = mxd;
     if (stats) {
