@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define STEPTH_ABI_VERSION 3u
+#define STEPTH_ABI_VERSION 4u
 
 typedef struct stepth_engine stepth_engine; /* opaque */
 
@@ -374,6 +374,14 @@ int stepth_get_stats_raw(stepth_engine *engine, uint64_t *out, uint32_t n);
  */
 int stepth_kernel_time_enable(stepth_engine *engine, int enable);
 int stepth_kernel_time_read(stepth_engine *engine, double *total_ms, uint64_t *launches);
+
+/*
+ * Self-test of the promise above that no call throws or aborts: raises a C++ exception inside
+ * the guard every status-returning entry point runs in, and returns what the guard made of it.
+ * kind 0: std::bad_alloc -> STEPTH_ERR_OUT_OF_MEMORY; 1: std::runtime_error, 2: a non-standard
+ * exception -> STEPTH_ERR_HIP; anything else: STEPTH_OK.  Needs no device (engine may be NULL).
+ */
+int stepth_selftest_exception_guard(stepth_engine *engine, int kind);
 
 #ifdef __cplusplus
 }

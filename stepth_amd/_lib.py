@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("STEPTH_AMD_LIB") or os.path.join(_HERE, "libstepth_amd.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "stepth_amd.h")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # stepth_status
 OK = 0
@@ -123,6 +123,7 @@ SYMBOLS = {
     "stepth_get_stats_raw": (C.c_int, [C.c_void_p, _P(C.c_uint64), C.c_uint32]),
     "stepth_kernel_time_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "stepth_kernel_time_read": (C.c_int, [C.c_void_p, _P(C.c_double), _P(C.c_uint64)]),
+    "stepth_selftest_exception_guard": (C.c_int, [C.c_void_p, C.c_int]),
 }
 
 

@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -126,6 +127,38 @@ void release(DevBuf &b)
     b.p = nullptr;
     b.cap = 0;
 }
+
+// The C-ABI promises that no call throws or aborts (include/stepth_amd.h): every extern "C"
+// entry with a status runs inside this guard -- a host allocation sized by caller input
+// (std::vector, std::string) that fails becomes STEPTH_ERR_OUT_OF_MEMORY instead of a
+// std::terminate in the caller's process.
+int guard_oom(stepth_engine *e) noexcept
+{
+    if (e) {
+        try {
+            e->err = "out of memory"; // (fits the small-string buffer: no allocation)
+        } catch (...) {
+        }
+    }
+    return STEPTH_ERR_OUT_OF_MEMORY;
+}
+
+int guard_other(stepth_engine *e, const char *what) noexcept
+{
+    try {
+        return fail(e, STEPTH_ERR_HIP, "unexpected C++ exception: %s", what);
+    } catch (...) {
+        return STEPTH_ERR_HIP;
+    }
+}
+
+#define STEPTH_GUARD_BEGIN try {
+#define STEPTH_GUARD_END(e)                                                                   \
+    }                                                                                         \
+    catch (const std::bad_alloc &) { return guard_oom(e); }                                   \
+    catch (const std::length_error &) { return guard_oom(e); }                                \
+    catch (const std::exception &ex_) { return guard_other((e), ex_.what()); }                \
+    catch (...) { return guard_other((e), "unknown"); }
 
 #define TRY(expr)                                                                             \
     do {                                                                                      \
@@ -729,6 +762,7 @@ const char *stepth_status_string(int status)
 
 int stepth_engine_create(int device_id, stepth_engine **out)
 {
+    STEPTH_GUARD_BEGIN
     if (!out)
         return STEPTH_ERR_BAD_ARG;
     *out = nullptr;
@@ -755,6 +789,7 @@ int stepth_engine_create(int device_id, stepth_engine **out)
     (void)hipMemsetAsync(e->stats, 0, kStatsBytes, e->stream);
     *out = e;
     return STEPTH_OK;
+    STEPTH_GUARD_END(nullptr)
 }
 
 void stepth_engine_destroy(stepth_engine *e)
@@ -792,6 +827,7 @@ void stepth_engine_destroy(stepth_engine *e)
 
 int stepth_host_alloc(void **out, size_t bytes)
 {
+    STEPTH_GUARD_BEGIN
     if (!out || bytes == 0)
         return STEPTH_ERR_BAD_ARG;
     *out = nullptr;
@@ -801,6 +837,7 @@ int stepth_host_alloc(void **out, size_t bytes)
     if (r == hipErrorNoDevice || r == hipErrorInvalidDevice)
         return STEPTH_ERR_NO_DEVICE;
     return r == hipSuccess ? STEPTH_OK : STEPTH_ERR_HIP;
+    STEPTH_GUARD_END(nullptr)
 }
 
 void stepth_host_free(void *ptr)
@@ -811,28 +848,34 @@ void stepth_host_free(void *ptr)
 
 int stepth_engine_set_stream(stepth_engine *e, void *hip_stream)
 {
+    STEPTH_GUARD_BEGIN
     if (!e)
         return STEPTH_ERR_BAD_ARG;
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     e->stream = static_cast<hipStream_t>(hip_stream); // nullptr = HIP's default stream
     return STEPTH_OK;
+    STEPTH_GUARD_END(e)
 }
 
 int stepth_engine_reset_stream(stepth_engine *e)
 {
+    STEPTH_GUARD_BEGIN
     if (!e)
         return STEPTH_ERR_BAD_ARG;
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     e->stream = e->own_stream;
     return STEPTH_OK;
+    STEPTH_GUARD_END(e)
 }
 
 int stepth_engine_sync(stepth_engine *e)
 {
+    STEPTH_GUARD_BEGIN
     if (!e)
         return STEPTH_ERR_BAD_ARG;
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     return STEPTH_OK;
+    STEPTH_GUARD_END(e)
 }
 
 const char *stepth_last_error(const stepth_engine *e) { return e ? e->err.c_str() : "null engine"; }
@@ -849,6 +892,7 @@ int stepth_depth_from_additional(stepth_engine *e, const stepth_image *main_im,
                                  uint32_t groups_memory, const stepth_image *depth_im,
                                  uint32_t *max_out)
 {
+    STEPTH_GUARD_BEGIN
     if (!e)
         return STEPTH_ERR_BAD_ARG;
     if (!pp || pp->struct_size != sizeof(stepth_params))
@@ -1138,6 +1182,7 @@ int stepth_depth_from_additional(stepth_engine *e, const stepth_image *main_im,
                     "every group's distance is 0; output is all zero (reference: divide by zero, "
                     "src/depth_image.rs:127)");
     return STEPTH_OK;
+    STEPTH_GUARD_END(e)
 }
 
 static int batch_host(stepth_engine *e, uint32_t n_frames, const stepth_image *mains,
@@ -1424,6 +1469,7 @@ int stepth_depth_from_additional_batch(stepth_engine *e, uint32_t n_frames,
                                        const stepth_params *pp, const stepth_image *depths,
                                        uint32_t *max_out)
 {
+    STEPTH_GUARD_BEGIN
     if (!e)
         return STEPTH_ERR_BAD_ARG;
     if (!pp || pp->struct_size != sizeof(stepth_params))
@@ -1625,6 +1671,7 @@ int stepth_depth_from_additional_batch(stepth_engine *e, uint32_t n_frames,
     if (!async && any_zero && !raw_only)
         return fail(e, STEPTH_ERR_MAX_ZERO, "a frame's distances are all 0; its output is all zero");
     return STEPTH_OK;
+    STEPTH_GUARD_END(e)
 }
 
 // Host-memory batch (what a caller holding decoded images in RAM has, src/depth_image.rs:8-9,
@@ -1759,6 +1806,7 @@ int stepth_normalise_rows_pattern(stepth_engine *e, const stepth_image *rows, ui
                                   uint32_t row_block, uint32_t row_mod, uint32_t row_rem,
                                   const uint32_t *max_ptr, uint32_t max_memory, uint32_t flags)
 {
+    STEPTH_GUARD_BEGIN
     if (!e)
         return STEPTH_ERR_BAD_ARG;
     TRY(check_image(e, rows, "rows", 1, 1));
@@ -1811,12 +1859,14 @@ int stepth_normalise_rows_pattern(stepth_engine *e, const stepth_image *rows, ui
     if (mx_host == 0)
         return fail(e, STEPTH_ERR_MAX_ZERO, "max is 0; rows zeroed");
     return STEPTH_OK;
+    STEPTH_GUARD_END(e)
 }
 
 int stepth_normalise_rows_batch(stepth_engine *e, uint32_t n_frames, const stepth_image *rows,
                                 uint32_t first_row, uint32_t row_block, uint32_t row_mod,
                                 uint32_t row_rem, const uint32_t *max_ptr, uint32_t flags)
 {
+    STEPTH_GUARD_BEGIN
     if (!e)
         return STEPTH_ERR_BAD_ARG;
     if (n_frames == 0 || !rows || !max_ptr)
@@ -1849,17 +1899,21 @@ int stepth_normalise_rows_batch(stepth_engine *e, uint32_t n_frames, const stept
     if (!(flags & STEPTH_FLAG_ASYNC))
         HIP_TRY(e, hipStreamSynchronize(e->stream));
     return STEPTH_OK;
+    STEPTH_GUARD_END(e)
 }
 
 int stepth_normalise_rows(stepth_engine *e, const stepth_image *rows, const uint32_t *max_ptr,
                           uint32_t max_memory, uint32_t flags)
 {
+    STEPTH_GUARD_BEGIN
     return stepth_normalise_rows_pattern(e, rows, 0, 0, 1, 0, max_ptr, max_memory, flags);
+    STEPTH_GUARD_END(e)
 }
 
 int stepth_gaussian_same_size(stepth_engine *e, const stepth_image *src, const stepth_image *dst,
                               uint32_t flags)
 {
+    STEPTH_GUARD_BEGIN
     if (!e)
         return STEPTH_ERR_BAD_ARG;
     TRY(check_image(e, src, "src", 1, 1));
@@ -1892,6 +1946,7 @@ int stepth_gaussian_same_size(stepth_engine *e, const stepth_image *src, const s
                                     hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     return STEPTH_OK;
+    STEPTH_GUARD_END(e)
 }
 
 int stepth_distance_dot_array_batch(stepth_engine *e, const stepth_image *array,
@@ -1899,6 +1954,7 @@ int stepth_distance_dot_array_batch(stepth_engine *e, const stepth_image *array,
                                     uint32_t max, const uint8_t precision[3], uint8_t *found,
                                     uint32_t *dist, uint32_t *pos_xy)
 {
+    STEPTH_GUARD_BEGIN
     if (!e)
         return STEPTH_ERR_BAD_ARG;
     TRY(check_image(e, array, "array", 3, 3));
@@ -1965,16 +2021,19 @@ int stepth_distance_dot_array_batch(stepth_engine *e, const stepth_image *array,
     HIP_TRY(e, hipMemcpyAsync(found, ra.found, n, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     return STEPTH_OK;
+    STEPTH_GUARD_END(e)
 }
 
 int stepth_stats_enable(stepth_engine *e, int enable)
 {
+    STEPTH_GUARD_BEGIN
     if (!e)
         return STEPTH_ERR_BAD_ARG;
     e->stats_enabled = enable != 0;
     e->stats_groups = 0;
     HIP_TRY(e, hipMemsetAsync(e->stats, 0, kStatsBytes, e->stream));
     return STEPTH_OK;
+    STEPTH_GUARD_END(e)
 }
 
 // the sum of the counters' replicas (ring_kernels.h stats_replica); synchronises the stream
@@ -1993,6 +2052,7 @@ static int read_stats(stepth_engine *e, unsigned long long (&sum)[kStatsWords])
 
 int stepth_get_stats(stepth_engine *e, stepth_stats *out)
 {
+    STEPTH_GUARD_BEGIN
     if (!e || !out)
         return STEPTH_ERR_BAD_ARG;
     if (!e->stats_enabled)
@@ -2007,10 +2067,12 @@ int stepth_get_stats(stepth_engine *e, stepth_stats *out)
     out->superblock_steps = h[4];
     out->blocks_probed = h[5];
     return STEPTH_OK;
+    STEPTH_GUARD_END(e)
 }
 
 int stepth_get_stats_raw(stepth_engine *e, uint64_t *out, uint32_t n)
 {
+    STEPTH_GUARD_BEGIN
     if (!e || !out || n > kStatsWords)
         return STEPTH_ERR_BAD_ARG;
     unsigned long long h[kStatsWords];
@@ -2018,20 +2080,24 @@ int stepth_get_stats_raw(stepth_engine *e, uint64_t *out, uint32_t n)
     for (uint32_t w = 0; w < n; ++w)
         out[w] = h[w];
     return STEPTH_OK;
+    STEPTH_GUARD_END(e)
 }
 
 int stepth_kernel_time_enable(stepth_engine *e, int enable)
 {
+    STEPTH_GUARD_BEGIN
     if (!e)
         return STEPTH_ERR_BAD_ARG;
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     e->timing = enable != 0;
     e->events_used = 0;
     return STEPTH_OK;
+    STEPTH_GUARD_END(e)
 }
 
 int stepth_kernel_time_read(stepth_engine *e, double *total_ms, uint64_t *launches)
 {
+    STEPTH_GUARD_BEGIN
     if (!e || !total_ms || !launches)
         return STEPTH_ERR_BAD_ARG;
     HIP_TRY(e, hipStreamSynchronize(e->stream));
@@ -2045,9 +2111,23 @@ int stepth_kernel_time_read(stepth_engine *e, double *total_ms, uint64_t *launch
     *launches = e->events_used;
     e->events_used = 0;
     return STEPTH_OK;
+    STEPTH_GUARD_END(e)
 }
 
 #include "zone_entries.h"
 #include "group_entries.h"
+
+int stepth_selftest_exception_guard(stepth_engine *e, int kind)
+{
+    STEPTH_GUARD_BEGIN
+    if (kind == 0)
+        throw std::bad_alloc();
+    if (kind == 1)
+        throw std::runtime_error("selftest");
+    if (kind == 2)
+        throw 42;
+    return STEPTH_OK;
+    STEPTH_GUARD_END(e)
+}
 
 } // extern "C"

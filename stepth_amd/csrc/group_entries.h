@@ -57,6 +57,7 @@ int stepth_adaptive_groups(stepth_engine *e, const stepth_image *main_im, const 
                            uint32_t min_splits, uint32_t max_splits, stepth_group *groups,
                            size_t capacity, uint32_t groups_memory, size_t *n_out)
 {
+    STEPTH_GUARD_BEGIN
     if (!e)
         return STEPTH_ERR_BAD_ARG;
     TRY(check_image(e, main_im, "main", 3, 4));
@@ -83,6 +84,7 @@ int stepth_adaptive_groups(stepth_engine *e, const stepth_image *main_im, const 
                               e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     return STEPTH_OK;
+    STEPTH_GUARD_END(e)
 }
 
 static int check_frames(stepth_engine *e, uint32_t n_frames, const stepth_image *mains,
@@ -115,6 +117,7 @@ int stepth_adaptive_groups_batch(stepth_engine *e, uint32_t n_frames, const step
                                  const uint8_t precision[3], uint32_t min_splits, uint32_t max_splits,
                                  stepth_group *const *groups_out, size_t capacity, size_t *n_out)
 {
+    STEPTH_GUARD_BEGIN
     if (!e)
         return STEPTH_ERR_BAD_ARG;
     if (n_frames == 0 || !mains || !precision || !groups_out || !n_out)
@@ -141,6 +144,7 @@ int stepth_adaptive_groups_batch(stepth_engine *e, uint32_t n_frames, const step
             n_out[f0 + f] = cnt[(size_t)4 * kGroupCtrPad * f];
     }
     return STEPTH_OK;
+    STEPTH_GUARD_END(e)
 }
 
 int stepth_depth_from_groups_batch(stepth_engine *e, uint32_t n_frames, const stepth_image *mains,
@@ -148,6 +152,7 @@ int stepth_depth_from_groups_batch(stepth_engine *e, uint32_t n_frames, const st
                                    const stepth_group *const *groups, const size_t *n_groups,
                                    const stepth_image *depths, uint32_t *max_out)
 {
+    STEPTH_GUARD_BEGIN
     if (!e)
         return STEPTH_ERR_BAD_ARG;
     if (!pp || pp->struct_size != sizeof(stepth_params))
@@ -185,4 +190,5 @@ int stepth_depth_from_groups_batch(stepth_engine *e, uint32_t n_frames, const st
     if (!(p.flags & STEPTH_FLAG_ASYNC) && any_zero && !(p.flags & STEPTH_FLAG_RAW_ONLY))
         return fail(e, STEPTH_ERR_MAX_ZERO, "a frame's distances are all 0; its output is all zero");
     return STEPTH_OK;
+    STEPTH_GUARD_END(e)
 }

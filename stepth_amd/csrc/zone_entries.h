@@ -141,6 +141,7 @@ static int async_needs_device(stepth_engine *e, uint32_t flags, std::initializer
 
 int stepth_invert_depth(stepth_engine *e, const stepth_image *depth, uint32_t flags)
 {
+    STEPTH_GUARD_BEGIN
     if (!e)
         return STEPTH_ERR_BAD_ARG;
     TRY(check_image(e, depth, "depth", 1, 1));
@@ -157,6 +158,7 @@ int stepth_invert_depth(stepth_engine *e, const stepth_image *depth, uint32_t fl
     HIP_TRY(e, hipGetLastError());
     OutPlane o{const_cast<uint8_t *>(d_src), ss, depth->memory == STEPTH_MEM_HOST};
     return finish_plane(e, *depth, o, flags & STEPTH_FLAG_ASYNC);
+    STEPTH_GUARD_END(e)
 }
 
 static void zone_from_table(const ZoneTable &t, uint32_t i, stepth_zone &z)
@@ -185,6 +187,7 @@ static int zones_to_host(stepth_engine *e, uint32_t zones, stepth_zone *out, uin
 int stepth_depth_split(stepth_engine *e, const stepth_image *depth, uint32_t zones, stepth_zone *out,
                        uint32_t capacity, uint32_t *n_out)
 {
+    STEPTH_GUARD_BEGIN
     if (!e)
         return STEPTH_ERR_BAD_ARG;
     TRY(check_image(e, depth, "depth", 1, 1));
@@ -204,11 +207,13 @@ int stepth_depth_split(stepth_engine *e, const stepth_image *depth, uint32_t zon
     TRY(to_device(e, *depth, e->gauss_io, d_src, ss));
     TRY(split_device(e, 1, &d_src, ss, depth->width, depth->height, zones));
     return zones_to_host(e, zones, out, capacity, n_out);
+    STEPTH_GUARD_END(e)
 }
 
 int stepth_depth_histogram(stepth_engine *e, const stepth_image *depth, uint32_t *counts,
                            uint32_t counts_memory, uint32_t flags)
 {
+    STEPTH_GUARD_BEGIN
     if (!e)
         return STEPTH_ERR_BAD_ARG;
     TRY(check_image(e, depth, "depth", 1, 1));
@@ -229,11 +234,13 @@ int stepth_depth_histogram(stepth_engine *e, const stepth_image *depth, uint32_t
     if (!async)
         HIP_TRY(e, hipStreamSynchronize(e->stream));
     return STEPTH_OK;
+    STEPTH_GUARD_END(e)
 }
 
 int stepth_zones_from_histogram(stepth_engine *e, const uint32_t *counts, uint32_t counts_memory,
                                 uint32_t zones, stepth_zone *out, uint32_t capacity, uint32_t *n_out)
 {
+    STEPTH_GUARD_BEGIN
     if (!e)
         return STEPTH_ERR_BAD_ARG;
     if (!counts || !out || !n_out || capacity == 0 ||
@@ -259,11 +266,13 @@ int stepth_zones_from_histogram(stepth_engine *e, const uint32_t *counts, uint32
                        static_cast<ZoneTable *>(e->zone_tables.p));
     HIP_TRY(e, hipGetLastError());
     return zones_to_host(e, zones, out, capacity, n_out);
+    STEPTH_GUARD_END(e)
 }
 
 int stepth_slice(stepth_engine *e, const stepth_image *depth, const stepth_zone *range,
                  const stepth_image *mask, uint32_t flags)
 {
+    STEPTH_GUARD_BEGIN
     if (!e)
         return STEPTH_ERR_BAD_ARG;
     TRY(check_image(e, depth, "depth", 1, 1));
@@ -282,11 +291,13 @@ int stepth_slice(stepth_engine *e, const stepth_image *depth, const stepth_zone 
     const uint32_t to = range->has_to ? range->to : 255u;      // :232
     TRY(slice_device(e, 1, &d_src, ss, &o.d, o.stride, depth->width, depth->height, from, to, false));
     return finish_plane(e, *mask, o, flags & STEPTH_FLAG_ASYNC);
+    STEPTH_GUARD_END(e)
 }
 
 int stepth_select_foreground(stepth_engine *e, const stepth_image *depth, const stepth_image *mask,
                              stepth_zone *zone_out)
 {
+    STEPTH_GUARD_BEGIN
     if (!e)
         return STEPTH_ERR_BAD_ARG;
     TRY(check_image(e, depth, "depth", 1, 1));
@@ -308,12 +319,14 @@ int stepth_select_foreground(stepth_engine *e, const stepth_image *depth, const 
     if (zone_out)
         zone_from_table(t, 0, *zone_out);
     return finish_plane(e, *mask, o, false);
+    STEPTH_GUARD_END(e)
 }
 
 int stepth_select_foreground_batch(stepth_engine *e, uint32_t n_frames, const stepth_image *depths,
                                    const stepth_image *masks, stepth_zone *zones_out, int *statuses,
                                    uint32_t flags)
 {
+    STEPTH_GUARD_BEGIN
     if (!e)
         return STEPTH_ERR_BAD_ARG;
     if (n_frames == 0 || !depths || !masks)
@@ -359,11 +372,13 @@ int stepth_select_foreground_batch(stepth_engine *e, uint32_t n_frames, const st
     if (first_bad != STEPTH_OK)
         return fail(e, first_bad, "select_foreground_batch: %s", stepth_status_string(first_bad));
     return STEPTH_OK;
+    STEPTH_GUARD_END(e)
 }
 
 int stepth_apply_mask(stepth_engine *e, const stepth_image *rgba, const stepth_image *mask,
                       uint32_t flags)
 {
+    STEPTH_GUARD_BEGIN
     if (!e)
         return STEPTH_ERR_BAD_ARG;
     TRY(check_image(e, rgba, "rgba", 4, 4));
@@ -388,4 +403,5 @@ int stepth_apply_mask(stepth_engine *e, const stepth_image *rgba, const stepth_i
     HIP_TRY(e, hipGetLastError());
     OutPlane o{const_cast<uint8_t *>(d_rgba), rs, rgba->memory == STEPTH_MEM_HOST};
     return finish_plane(e, *rgba, o, flags & STEPTH_FLAG_ASYNC);
+    STEPTH_GUARD_END(e)
 }

@@ -36,7 +36,7 @@ def test_header_symbols_all_exported_and_bound(lib):
 
 def test_abi_version_and_status_strings(lib):
     from stepth_amd import _lib
-    assert lib.stepth_abi_version() == _lib.ABI_VERSION == 3
+    assert lib.stepth_abi_version() == _lib.ABI_VERSION == 4
     # the reference's fixed error text, src/depth_image.rs:45-48
     assert lib.stepth_status_string(_lib.ERR_SIZE_MISMATCH) == b"Sizes don't match"
     assert lib.stepth_status_string(0) == b"ok"
@@ -62,6 +62,31 @@ def test_null_arguments_fail_cleanly_without_a_device(lib):
     assert lib.stepth_engine_sync(None) == _lib.ERR_BAD_ARG
     assert lib.stepth_last_error(None) == b"null engine"
     lib.stepth_engine_destroy(None)  # no-op
+
+
+def test_no_exception_crosses_the_c_abi(lib):
+    """include/stepth_amd.h: "calls never throw or abort".  Every status-returning entry runs
+    inside the exception guard (source scan), and the guard turns a failed host allocation into
+    STEPTH_ERR_OUT_OF_MEMORY and anything else into STEPTH_ERR_HIP (self-test entry, no device)"""
+    from stepth_amd import _lib
+    assert lib.stepth_selftest_exception_guard(None, 0) == _lib.ERR_OUT_OF_MEMORY
+    assert lib.stepth_selftest_exception_guard(None, 1) == _lib.ERR_HIP
+    assert lib.stepth_selftest_exception_guard(None, 2) == _lib.ERR_HIP
+    assert lib.stepth_selftest_exception_guard(None, 3) == 0
+    csrc = os.path.join(ROOT, "stepth_amd", "csrc")
+    seen = set()
+    for f in os.listdir(csrc):
+        if not f.endswith((".hip", ".h")):
+            continue
+        text = open(os.path.join(csrc, f)).read()
+        for m in re.finditer(r"^int (stepth_\w+)\([^;{]*\)\n\{\n(.*?)^\}", text, flags=re.S | re.M):
+            seen.add(m.group(1))
+            body = m.group(2)
+            assert body.lstrip().startswith("STEPTH_GUARD_BEGIN") and "STEPTH_GUARD_END(" in body.rstrip().splitlines()[-1], m.group(1)
+    status_entries = {n for n in declared_functions()
+                      if n not in ("stepth_abi_version", "stepth_status_string", "stepth_last_error",
+                                   "stepth_engine_destroy", "stepth_host_free")}
+    assert seen == status_entries, (sorted(status_entries - seen), sorted(seen - status_entries))
 
 
 def test_engine_fails_loudly_without_gpu():
