@@ -143,7 +143,8 @@ int stepth_engine_create(int device_id, stepth_engine **out);
 void stepth_engine_destroy(stepth_engine *engine);
 /* Run on the caller's HIP stream (a hipStream_t; NULL is HIP's default stream, which is what
  * torch.cuda.current_stream() usually is) instead of the engine's own non-blocking stream;
- * stepth_engine_reset_stream() goes back to the engine's own.  Both drain the old stream. */
+ * stepth_engine_reset_stream() goes back to the engine's own.  The new stream is ordered after
+ * whatever the old one still holds (an event it waits for); the host is not blocked. */
 int stepth_engine_set_stream(stepth_engine *engine, void *hip_stream);
 int stepth_engine_reset_stream(stepth_engine *engine);
 int stepth_engine_sync(stepth_engine *engine);

@@ -65,6 +65,7 @@ struct stepth_engine {
     // host-image batches: two slots of device staging, copy streams and events (batch_host)
     DevBuf pipe_main[2], pipe_add[2], pipe_out[2], pipe_max;
     hipStream_t copy_in = nullptr, copy_out = nullptr;
+    hipEvent_t ev_switch = nullptr; // orders a newly bound stream after the old one's work
     hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_compute[2] = {nullptr, nullptr},
                ev_out[2] = {nullptr, nullptr};
     uint32_t *words = nullptr; // layout: kWord* above
@@ -306,6 +307,10 @@ int pack_additional_tiles(stepth_engine *e, uint32_t n_frames, const uint8_t *co
         e->bbp_layout[2] < n_frames) {
         // the border around the image's blocks must be empty bounds (min = kNoCell, never matching)
         HIP_TRY(e, hipMemsetD32Async((hipDeviceptr_t)e->BBp.p, (int)kNoCell, bb_frame * 2 * n_frames, e->stream));
+        // and so is every superblock until tile_super_kernel has folded it: a strip call leaves
+        // the rows outside its reach as they are -- empty, or an earlier image's bounds, never
+        // allocator contents (the search's own dmin tests keep both from being probed)
+        HIP_TRY(e, hipMemsetD32Async((hipDeviceptr_t)e->SBp.p, (int)kNoCell, sb_frame * 2 * n_frames, e->stream));
         e->bbp_layout[0] = bw;
         e->bbp_layout[1] = bh;
         e->bbp_layout[2] = n_frames;
@@ -806,7 +811,7 @@ void stepth_engine_destroy(stepth_engine *e)
                       &e->group_list[0], &e->group_list[1], &e->group_list[2], &e->group_counters, &e->order_bytes, &e->order_words})
         release(*b);
     for (hipEvent_t ev : {e->ev_in[0], e->ev_in[1], e->ev_compute[0], e->ev_compute[1], e->ev_out[0],
-                          e->ev_out[1]})
+                          e->ev_out[1], e->ev_switch})
         if (ev)
             (void)hipEventDestroy(ev);
     for (hipStream_t st : {e->copy_in, e->copy_out})
@@ -846,14 +851,27 @@ void stepth_host_free(void *ptr)
         (void)hipHostFree(ptr);
 }
 
+// The engine's work moves to another stream: what the old stream still holds is ordered before
+// whatever the new one gets (an event the new stream waits for -- the host is not blocked).
+static int switch_stream(stepth_engine *e, hipStream_t to)
+{
+    if (to == e->stream)
+        return STEPTH_OK;
+    HIP_TRY(e, hipSetDevice(e->device));
+    if (!e->ev_switch)
+        HIP_TRY(e, hipEventCreateWithFlags(&e->ev_switch, hipEventDisableTiming));
+    HIP_TRY(e, hipEventRecord(e->ev_switch, e->stream));
+    HIP_TRY(e, hipStreamWaitEvent(to, e->ev_switch, 0));
+    e->stream = to;
+    return STEPTH_OK;
+}
+
 int stepth_engine_set_stream(stepth_engine *e, void *hip_stream)
 {
     STEPTH_GUARD_BEGIN
     if (!e)
         return STEPTH_ERR_BAD_ARG;
-    HIP_TRY(e, hipStreamSynchronize(e->stream));
-    e->stream = static_cast<hipStream_t>(hip_stream); // nullptr = HIP's default stream
-    return STEPTH_OK;
+    return switch_stream(e, static_cast<hipStream_t>(hip_stream)); // nullptr = HIP's default stream
     STEPTH_GUARD_END(e)
 }
 
@@ -862,9 +880,7 @@ int stepth_engine_reset_stream(stepth_engine *e)
     STEPTH_GUARD_BEGIN
     if (!e)
         return STEPTH_ERR_BAD_ARG;
-    HIP_TRY(e, hipStreamSynchronize(e->stream));
-    e->stream = e->own_stream;
-    return STEPTH_OK;
+    return switch_stream(e, e->own_stream);
     STEPTH_GUARD_END(e)
 }
 

@@ -82,14 +82,27 @@ __device__ __forceinline__ void adaptive_visit(const AdaptiveArgs &a, uint32_t f
             const bool by_dwords = a.ch == 3u && ((reinterpret_cast<uintptr_t>(a.px[f]) | a.stride) & 3u) == 0u;
             if (by_dwords) {
                 const uint32_t b0 = n.x * 3u, b1 = (n.x + n.w) * 3u, a0 = b0 & ~3u; // bytes of the row
+                const uint32_t row_bytes = a.W * 3u;
                 uint32_t tmn[3] = {255, 255, 255}, tmx[3] = {0, 0, 0}, tsum[3] = {0, 0, 0};
                 for (uint32_t yy = n.y; yy < n.y + n.h; ++yy) {
                     const uint8_t *row = a.px[f] + (size_t)yy * a.stride;
                     for (uint32_t o = a0; o < b1; o += 12u) {
                         uint32_t dw[3]; // the three loads go out together
 #pragma unroll
-                        for (uint32_t i = 0; i < 3; ++i)
-                            dw[i] = o + 4u * i < b1 ? *reinterpret_cast<const uint32_t *>(row + o + 4u * i) : 0u;
+                        for (uint32_t i = 0; i < 3; ++i) {
+                            const uint32_t od = o + 4u * i;
+                            dw[i] = 0u;
+                            if (od + 4u <= row_bytes) { // whole dword inside the row
+                                if (od < b1)
+                                    dw[i] = *reinterpret_cast<const uint32_t *>(row + od);
+                            } else if (od < b1) { // the row's last bytes: never read past the image
+                                dw[i] = row[od];
+                                if (od + 1u < row_bytes)
+                                    dw[i] |= (uint32_t)row[od + 1u] << 8;
+                                if (od + 2u < row_bytes)
+                                    dw[i] |= (uint32_t)row[od + 2u] << 16;
+                            }
+                        }
 #pragma unroll
                         for (uint32_t i = 0; i < 3; ++i)
 #pragma unroll

@@ -118,6 +118,7 @@ static int out_plane(stepth_engine *e, const stepth_image &im, DevBuf &stage, Ou
     o.staged = true;
     return STEPTH_OK;
 }
+
 static int finish_plane(stepth_engine *e, const stepth_image &im, const OutPlane &o, bool async)
 {
     if (async)

@@ -145,26 +145,35 @@ class Engine:
         raise kind(st, msg)
 
     def set_stream(self, hip_stream: int):
-        """Run on this hipStream_t handle (0 = HIP's default stream)."""
-        if getattr(self, "_bound", None) != hip_stream:
-            self._bound = None  # an explicit choice; _follow() rebinds when torch's stream differs
+        """Run on this hipStream_t handle (0 = HIP's default stream) -- an explicit choice: it
+        holds for every later call, CUDA tensors or not, until reset_stream() or
+        use_torch_stream().  (The new stream waits for what the old one holds; the host does not.)"""
+        self._explicit = True
+        self._bound = hip_stream
         self._check(self._lib.stepth_engine_set_stream(self._h, hip_stream or None))
 
     def reset_stream(self):
-        """Back to the engine's own non-blocking stream."""
+        """Back to the engine's own non-blocking stream, and to following torch's current stream
+        for calls with CUDA tensors."""
+        self._explicit = False
         self._bound = None
         self._check(self._lib.stepth_engine_reset_stream(self._h))
 
     def use_torch_stream(self):
+        """Bind to torch's current stream now, and keep following it from call to call."""
         import torch
+        self._explicit = False
         self._bound = torch.cuda.current_stream().cuda_stream
-        self.set_stream(self._bound)
+        self._check(self._lib.stepth_engine_set_stream(self._h, self._bound or None))
 
     def _follow(self, *args):
-        """Calls whose arguments are CUDA tensors run on torch's CURRENT stream: whatever
-        produced the tensors (fills, earlier kernels, collectives) is ordered before the
-        engine's kernels and whatever consumes the results after them.  The engine's own
-        non-blocking stream serves numpy (host-memory) calls, which synchronise themselves."""
+        """Unless set_stream() made an explicit choice, calls whose arguments are CUDA tensors
+        run on torch's CURRENT stream: whatever produced the tensors (fills, earlier kernels,
+        collectives) is ordered before the engine's kernels and whatever consumes the results
+        after them.  The engine's own non-blocking stream serves numpy (host-memory) calls,
+        which synchronise themselves."""
+        if getattr(self, "_explicit", False):
+            return
         for a in args:
             if isinstance(a, (list, tuple)):
                 a = a[0] if a else None
@@ -173,7 +182,8 @@ class Engine:
                 cur = torch.cuda.current_stream(a.device).cuda_stream
                 if getattr(self, "_bound", None) != cur:
                     self._bound = cur
-                    self.set_stream(cur)  # (syncs the stream used before)
+                    # (device-side ordering after the stream used before; no host wait)
+                    self._check(self._lib.stepth_engine_set_stream(self._h, cur or None))
                 return
 
     def sync(self):

@@ -252,7 +252,12 @@ class EngineStripWorker(StripWorker):
         from .engine import PlaneList
         key = id(frames)
         hit = self._sets.get(key)
-        if hit is None or hit[0] is not frames:
+        # a hit must be the same tensors, not just the same list object: a caller that refills
+        # one list in place (frames[i] = new pair, the natural video loop) gets new descriptions
+        if hit is not None and not (hit[0] is frames and len(hit[6]) == len(frames) and
+                                    all(f[0] is p[0] and f[1] is p[1] for f, p in zip(frames, hit[6]))):
+            hit = None
+        if hit is None:
             mains = PlaneList([f[0] for f in frames], (3, 4), "main")
             adds = PlaneList([f[1] for f in frames], (3,), "additional")
             h, w = frames[0][0].shape[0], frames[0][0].shape[1]
@@ -260,12 +265,12 @@ class EngineStripWorker(StripWorker):
             outs = PlaneList([base[i] for i in range(len(frames))], (1,), "depth")
             if len(self._sets) > 8:
                 self._sets.clear()
-            hit = self._sets[key] = (frames, mains, adds, base, outs, {})
+            hit = self._sets[key] = (frames, mains, adds, base, outs, {}, [(f[0], f[1]) for f in frames])
         return hit
 
     def match_batch(self, frames, rows, pattern=None):
         """PASS 1 for every frame -> (list of raw views [r1-r0, W], max int32 [F])."""
-        _f, mains, adds, base, fulls, _views = self._described(frames)
+        _f, mains, adds, base, fulls, _views, _pairs = self._described(frames)
         dev = base.device
         mx = torch.zeros(len(frames), dtype=torch.int32, device=dev)
         if rows[1] > rows[0]:
@@ -288,7 +293,7 @@ class EngineStripWorker(StripWorker):
     def depth_batch(self, frames):
         """the whole path for every frame in one batched call (one rank: nothing to exchange
         between PASS 1 and PASS 2) -> (depth u8 [F, H, W], max int32 [F])"""
-        _f, mains, adds, base, outs, _views = self._described(frames)
+        _f, mains, adds, base, outs, _views, _pairs = self._described(frames)
         mx = torch.zeros(len(frames), dtype=torch.int32, device=base.device)
         self.engine.depth_from_additional_batch(mains, adds, self.precision,
                                                 max_steps=self.kw["max_steps"], mode=self.kw["mode"],

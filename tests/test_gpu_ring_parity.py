@@ -924,3 +924,79 @@ def test_heavy_first_launch_order_changes_nothing_but_the_order(engine, oracle, 
     engine.depth_from_additional(nat[0], nat[1], P36, max_steps=128, rows=(135, 1080), raw_only=True, out=out0)
     engine.depth_from_additional(nat[0], nat[1], P36, max_steps=128, rows=(135, 1080), raw_only=True, out=out1, heavy_first=True)
     assert np.array_equal(out0, out1) and out0[135:].any()
+
+
+def test_group_list_with_empty_rectangles(engine, oracle):
+    """a group of zero width or height paints nothing (like the reference's collect()) but is
+    still matched and counts for the max (src/depth_image.rs:112-124); host and device lists"""
+    import torch
+    from stepth_amd import synth
+    l, r, _ = synth.stereo_pair(96, 64, 24, seed=21)
+    g = oracle.uniform_groups(l, 8, 8).copy()
+    extra = np.zeros(4, oracle.GROUP_DTYPE)
+    extra["x"], extra["y"] = [10, 40, 95, 0], [5, 20, 63, 0]
+    extra["w"], extra["h"] = [0, 5, 0, 0], [3, 0, 0, 0]
+    extra["value"] = [[250, 5, 5], [5, 250, 5], [1, 2, 3], [200, 200, 200]]  # colours that match far away or never
+    g = np.concatenate([g[:20], extra, g[20:]])
+    ref = run_both(engine, oracle, l, r, P36, groups=g)
+    # the batched entry with the list in device memory (it cannot be validated on the host)
+    mains, adds = [torch.from_numpy(l).cuda()], [torch.from_numpy(r).cuda()]
+    gd = torch.from_numpy(g.view(np.uint8).reshape(-1, 20).copy()).cuda()
+    outs, mx = engine.depth_from_groups_batch(mains, adds, P36, [gd], [len(g)])
+    assert mx == [ref["max"]]
+    np.testing.assert_array_equal(outs[0].cpu().numpy(), ref["depth"])
+
+
+def test_explicit_stream_choice_is_kept_and_switches_do_not_block(engine, oracle):
+    """set_stream() is an explicit choice: CUDA-tensor calls stay on it whatever torch's current
+    stream is, until reset_stream(); binding another stream orders it after the old one's work
+    on the device (the result of a call enqueued right after a switch is still the oracle's)"""
+    import torch
+    from stepth_amd import synth
+    l, r, _ = synth.stereo_pair(320, 180, 32, seed=5)
+    ref = oracle.depth_from_additional(l, r, P36, 255)
+    tl, tr = torch.from_numpy(l).cuda(), torch.from_numpy(r).cuda()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    try:
+        engine.set_stream(s1.cuda_stream)
+        with torch.cuda.stream(s2):  # torch's current stream differs: the explicit choice wins
+            a, _ = engine.depth_from_additional_batch([tl], [tr], P36, asynchronous=True)
+        assert engine._bound == s1.cuda_stream
+        s1.synchronize()
+        np.testing.assert_array_equal(a[0].cpu().numpy(), ref["depth"])
+        for s in (s2, s1, s2):  # alternate: every switch is an event wait, results stay right
+            engine.set_stream(s.cuda_stream)
+            b, _ = engine.depth_from_additional_batch([tl], [tr], P36, asynchronous=True)
+        s2.synchronize()
+        np.testing.assert_array_equal(b[0].cpu().numpy(), ref["depth"])
+    finally:
+        engine.reset_stream()
+    with torch.cuda.stream(s2):  # following torch's current stream again
+        c, _ = engine.depth_from_additional_batch([tl], [tr], P36, asynchronous=True)
+        assert engine._bound == s2.cuda_stream
+    s2.synchronize()
+    np.testing.assert_array_equal(c[0].cpu().numpy(), ref["depth"])
+    engine.reset_stream()
+
+
+def test_strip_worker_notices_a_frame_list_refilled_in_place(engine, oracle):
+    """EngineStripWorker caches the descriptions of a frame set by list object; a caller that
+    puts new tensors into the same list must not get the old frames' depth maps"""
+    import torch
+    from stepth_amd import synth
+    from stepth_amd.sharding import EngineStripWorker
+    engine.use_torch_stream()
+    w = EngineStripWorker(engine, P36, max_steps=64, tile=(1, 1), mode=0)
+    pairs = [synth.stereo_pair(160, 96, 24, seed=s)[:2] for s in (1, 2, 3)]
+    frames = [(torch.from_numpy(pairs[0][0]).cuda(), torch.from_numpy(pairs[0][1]).cuda()),
+              (torch.from_numpy(pairs[1][0]).cuda(), torch.from_numpy(pairs[1][1]).cuda())]
+    d0, _ = w.depth_batch(frames)
+    first = d0.cpu().numpy().copy()
+    frames[1] = (torch.from_numpy(pairs[2][0]).cuda(), torch.from_numpy(pairs[2][1]).cuda())  # same list object
+    d1, _ = w.depth_batch(frames)
+    got = d1.cpu().numpy()
+    for f, p in ((0, pairs[0]), (1, pairs[2])):
+        np.testing.assert_array_equal(got[f], oracle.depth_from_additional(p[0], p[1], P36, 64)["depth"])
+    np.testing.assert_array_equal(first[1], oracle.depth_from_additional(pairs[1][0], pairs[1][1], P36, 64)["depth"])
+    engine.reset_stream()
