@@ -1316,7 +1316,17 @@ __global__ __launch_bounds__(256) void gauss_horizontal4_kernel(Gauss4Args a)
 __global__ __launch_bounds__(256) void zero_rows_kernel(PaintArgs a)
 {
     uint8_t *out = a.out[blockIdx.y];
-    const size_t total = (size_t)(a.row_end - a.row_begin) * a.w;
+    const uint32_t rows = a.row_end - a.row_begin;
+    if (((reinterpret_cast<uintptr_t>(out) | a.ostride | a.w) & 15u) == 0) { // 16 bytes per lane
+        const uint32_t w16 = a.w >> 4;
+        const size_t total = (size_t)rows * w16;
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+            const uint32_t r = (uint32_t)(i / w16), c = (uint32_t)(i - (size_t)r * w16);
+            *reinterpret_cast<uint4 *>(out + (size_t)(a.row_begin + r) * a.ostride + 16u * c) = make_uint4(0u, 0u, 0u, 0u);
+        }
+        return;
+    }
+    const size_t total = (size_t)rows * a.w;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (size_t)gridDim.x * blockDim.x)
         out[(size_t)(a.row_begin + (uint32_t)(i / a.w)) * a.ostride + (i % a.w)] = 0;

@@ -654,10 +654,29 @@ __device__ __forceinline__ uint32_t test_row_v(uint32_t acc, const ulonglong2 &v
 constexpr uint64_t kNearLe[4] = {0x0000000008000000ull, 0x0000001C1C1C0000ull,
                                  0x00003E3E3E3E3E00ull, 0x007F7F7F7F7F7F7Full};
 
+// Probe tasks (round 3).  The windows' bound tests tell every lane which blocks ITS query must
+// look into.  Until round 3 each lane then probed its own blocks one after the other, and the wave
+// sat through a ~300-instruction probe whenever any lane had one: 23 of 64 lanes worked per
+// instruction, the kernel was bound by its slowest waves (2.5 of 8 wave slots filled, VALU 45 %
+// busy).  Now a candidate (query, block) pair is a TASK in a wave-level pool in LDS; tasks are
+// executed 64 at a time by whichever lanes -- query box, centre, best key and limit come from LDS,
+// an improvement merges back by minimum -- once the pool holds kListFlushMin of them (waiting
+// longer lets limits go stale and queues probes a hit has made useless), before it could
+// overflow, before the own-window results are judged and when the search ends.  The result is
+// the same: a block is skipped only if its nearest cell lies at or beyond the query's limit of
+// that moment.
+constexpr uint32_t kListPoolCap = 128, kListFlushMin = 16;
+
 template <bool STATS>
-__global__ __launch_bounds__(256) void ring_list_kernel(ListArgs a)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void ring_list_kernel(ListArgs a)
 {
+    __shared__ uint2 s_box[4][64];            // per wave: the queries as the tasks see them: box {lo, hi},
+    __shared__ uint2 s_qxy[4][64];            // centre,
+    __shared__ uint32_t s_best[4][64];        // smallest key so far (merged by minimum),
+    __shared__ uint32_t s_lim[4][64];         // its limit;
+    __shared__ uint32_t s_task[4][kListPoolCap]; // the pool: query lane | block x << 6 | block y << 19
     const uint32_t lane = threadIdx.x & 63u, f = blockIdx.y;
+    const uint32_t wv = rfl(threadIdx.x >> 6);
     // a wave takes `lanes` (16, 32 or 64) consecutive queries: a small launch is bound by the
     // latency of its slowest wave, not by issue slots, and a wave of fewer queries has fewer
     // windows to sit through
@@ -695,110 +714,57 @@ __global__ __launch_bounds__(256) void ring_list_kernel(ListArgs a)
             n_ring0 = q.best == 0u;
     }
 
-    // probes the blocks of `cand` (window origin (bx0, by0)) in the order of their bits
-    auto probe_candidates = [&](uint64_t cur, int bx0, int by0) __attribute__((always_inline)) {
-        while (cur != 0ull) {
-            const int k = __builtin_ctzll(cur);
-            cur &= cur - 1ull;
-            const int bx = bx0 + (k & 7), by = by0 + (k >> 3);
-            const int x0 = bx * 8 - q.qx, y0 = by * 8 - q.qy;
-            // (the dmin test also keeps stale bounds of unpacked rows from being probed)
-            if ((uint32_t)square_dmin(x0, y0, 8) < q.limit) {
-                const uint32_t boff = tf + ((uint32_t)by * a.bw + (uint32_t)bx) * 64u;
-                const uint32_t nl = probe_block(q, x0, y0, pb, a.T + boff, a.TT + boff,
-                                                reinterpret_cast<const uint32_t *>(a.LB) + (boff >> 1));
-                if constexpr (STATS) {
-                    ++n_probed;
-                    n_tests += 8u * nl;
-                }
-            }
-        }
-    };
-
     if (__builtin_amdgcn_ballot_w64(q.limit != 0u)) {
-        // ---- the 7x7 blocks around the lane's own centre block (block-rings 0..3) ----
-        if (q.limit != 0u) {
-            if constexpr (STATS)
-                ++n_near;
-            uint32_t m_lo = 0, m_hi = 0; // bit row*8+col
-            const uint2 *win = BBf + (size_t)(cby - 3 + kPadB) * a.bwp + (size_t)(cbx - 3 + kPadB);
-#pragma unroll
-            for (int row = 6; row >= 4; --row) {
-                const ulonglong2 *rp4 = reinterpret_cast<const ulonglong2 *>(win + (size_t)row * a.bwp);
-                m_hi = test_row_v(m_hi, rp4[0], rp4[1], rp4[2], rp4[3], kq);
-            }
-#pragma unroll
-            for (int row = 3; row >= 0; --row) {
-                const ulonglong2 *rp4 = reinterpret_cast<const ulonglong2 *>(win + (size_t)row * a.bwp);
-                m_lo = test_row_v(m_lo, rp4[0], rp4[1], rp4[2], rp4[3], kq);
-            }
-            if constexpr (STATS)
-                n_tests += 56u;
-            const uint64_t cand = (((uint64_t)m_hi << 32) | m_lo) & kNearLe[3];
-            for (int ps = 0; ps < 4; ++ps) {
-                if (8 * (ps - 1) + 1 >= (int)q.limit)
-                    break;
-                probe_candidates(cand & kNearLe[ps] & ~(ps ? kNearLe[ps - 1] : 0ull), cbx - 3, cby - 3);
-            }
-            // settled: best ring <= 24, or nothing beyond ring 24 to search
-            if (s_end <= 25u || (q.best != kTileNoKey && (q.best >> ring_shift) <= 24u))
-                q.limit = 0u;
-        }
-    }
-
-    if (__builtin_amdgcn_ballot_w64(q.limit != 0u)) {
-        // ---- far phase.  The lanes still searching share what they can: the bounding box of
-        // their centres gives ONE window of superblocks for the wave, surveyed and visited
-        // nearest first like in ring_tile_kernel (bounds by scalar loads, every lane against its
-        // own box and its own distance).  Only when the queries of a wave are spread so far
-        // apart that the window does not fit the slots does each lane walk its own window.
+        s_box[wv][lane] = make_uint2(q.lo, q.hi);
+        s_qxy[wv][lane] = make_uint2((uint32_t)q.qx, (uint32_t)q.qy);
+        uint32_t n_pool = 0; // tasks in the pool (wave-uniform)
+        // shared far phase: ONE window of superblocks for the wave (see mode 1 below)
+        int sx0 = 0, sy0 = 0, nsx = 0, nsy = 0, wx_lo = 0, wy_lo = 0, wx_hi = 0, wy_hi = 0, mx = 0, my = 0;
+        uint32_t tol = 0, skey0 = kTileNoKey, skey1 = kTileNoKey, skey2 = kTileNoKey; // slot ty*16+tx
+        // spread-out far phase: every lane walks its own window ring by ring (mode 2)
+        int lx0 = 0, ly0 = 0, lx1 = 0, ly1 = 0, scx = 0, scy = 0, ring = 0, rt = -1;
         const int R = (int)a.max_steps - 1;
-        const bool far = q.limit != 0u;
-        const int wx_lo = (int)wave_min_dpp(far ? (uint32_t)q.qx : 0x7fffffffu);
-        const int wy_lo = (int)wave_min_dpp(far ? (uint32_t)q.qy : 0x7fffffffu);
-        const int wx_hi = (int)wave_max_dpp(far ? (uint32_t)q.qx : 0u);
-        const int wy_hi = (int)wave_max_dpp(far ? (uint32_t)q.qy : 0u);
-        const int sx0 = max(wx_lo - R, 0) >> 6, sy0 = max(wy_lo - R, 0) >> 6;
-        const int sx1 = min(wx_hi + R, (int)a.wa - 1) >> 6, sy1 = min(wy_hi + R, (int)a.ha - 1) >> 6;
-        const int nsx = sx1 - sx0 + 1, nsy = sy1 - sy0 + 1;
-        if (nsx <= 10 && nsy <= 12) {
-            // middle of the box orders the visits; a lane's own distance differs by <= tol
-            const int mx = (wx_lo + wx_hi) >> 1, my = (wy_lo + wy_hi) >> 1;
-            const uint32_t tol = (uint32_t)max(wx_hi - mx, wy_hi - my) + 1u;
-            uint32_t skey0 = kTileNoKey, skey1 = kTileNoKey, skey2 = kTileNoKey; // slot ty*16+tx
-            for (int ty = 0; ty < nsy; ++ty) {
-                const int sy = sy0 + ty;
-                const uint32_t row_dw = reinterpret_cast<const uint32_t *>(SBf + (size_t)sy * a.sbwp + sx0)[lane & 31u];
-                const int ay = (sy << 6) - q.qy;
-                const int dsy = max(max(ay, -63 - ay), 0);
-                for (int tx = 0; tx < nsx; ++tx) { // (lane i holds dword i of the row, see ring_tile_kernel)
-                    const uint32_t bmax = (uint32_t)__builtin_amdgcn_readlane((int)row_dw, 2 * tx);
-                    const uint32_t bmin = (uint32_t)__builtin_amdgcn_readlane((int)row_dw, 2 * tx + 1);
-                    const int ax = ((sx0 + tx) << 6) - q.qx;
-                    const uint32_t dS = (uint32_t)max(max(max(ax, -63 - ax), 0), dsy);
-                    const bool w = dS < q.limit && box_meets(bmax, bmin, q.lo, q.hi);
+
+        // 0: the 7x7 blocks around the lane's own centre block, 1: the wave's window of
+        // superblocks nearest first, 2: per-lane windows, 3: only the pool is left
+        for (int mode = 0;;) {
+            uint64_t cand = 0ull; // blocks of the window the lane's query must look into
+            int ox = 0, oy = 0;   // the window's block (0,0), per lane
+            int rounds = 1;
+            if (mode == 0) {
+                // ---- the 7x7 blocks around the lane's own centre block (block-rings 0..3) ----
+                if (q.limit != 0u) {
                     if constexpr (STATS)
-                        n_tests += q.limit != 0u;
-                    if (__builtin_amdgcn_ballot_w64(w)) {
-                        const int rx = ((sx0 + tx) << 6) - mx, ry = (sy << 6) - my;
-                        const uint32_t dref = (uint32_t)max(max(max(rx, -63 - rx), max(ry, -63 - ry)), 0);
-                        const uint32_t t = (uint32_t)(ty * 16 + tx);
-                        const uint32_t key = (dref << 8) | t;
-                        if (lane == (t & 63u)) {
-                            if (t < 64u)
-                                skey0 = key;
-                            else if (t < 128u)
-                                skey1 = key;
-                            else
-                                skey2 = key;
-                        }
+                        ++n_near;
+                    uint32_t m_lo = 0, m_hi = 0; // bit row*8+col
+                    const uint2 *win = BBf + (size_t)(cby - 3 + kPadB) * a.bwp + (size_t)(cbx - 3 + kPadB);
+#pragma unroll
+                    for (int row = 6; row >= 4; --row) {
+                        const ulonglong2 *rp4 = reinterpret_cast<const ulonglong2 *>(win + (size_t)row * a.bwp);
+                        m_hi = test_row_v(m_hi, rp4[0], rp4[1], rp4[2], rp4[3], kq);
                     }
+#pragma unroll
+                    for (int row = 3; row >= 0; --row) {
+                        const ulonglong2 *rp4 = reinterpret_cast<const ulonglong2 *>(win + (size_t)row * a.bwp);
+                        m_lo = test_row_v(m_lo, rp4[0], rp4[1], rp4[2], rp4[3], kq);
+                    }
+                    if constexpr (STATS)
+                        n_tests += 56u;
+                    cand = (((uint64_t)m_hi << 32) | m_lo) & kNearLe[3];
+                    ox = cbx - 3;
+                    oy = cby - 3;
                 }
-            }
-            for (;;) {
+                rounds = 4;
+            } else if (mode == 1) {
+                // ---- the lanes still searching share what they can: the bounding box of their
+                // centres gives ONE window of superblocks for the wave, surveyed once and visited
+                // nearest first (bounds by scalar loads, every lane against its own box and its
+                // own distance) ----
                 const uint32_t pick = wave_min_dpp(min(min(skey0, skey1), skey2));
-                if (pick == kTileNoKey || (pick >> 8) >= wave_max_dpp(q.limit) + tol)
-                    break;
+                if (pick == kTileNoKey || (pick >> 8) >= wave_max_dpp(q.limit) + tol) {
+                    mode = 3; // (limits only shrink when the pooled tasks run: the search stays over)
+                    continue;
+                }
                 skey0 = skey0 == pick ? kTileNoKey : skey0;
                 skey1 = skey1 == pick ? kTileNoKey : skey1;
                 skey2 = skey2 == pick ? kTileNoKey : skey2;
@@ -848,27 +814,27 @@ __global__ __launch_bounds__(256) void ring_list_kernel(ListArgs a)
                 if constexpr (STATS)
                     n_tests += want ? 64u : 0u;
                 if (want) // the lane's own 7x7 window did block-rings 0..3 around ITS centre block
-                    probe_candidates((((uint64_t)m_hi << 32) | m_lo) & ~window_le_mask(bx0, by0, cbx, cby, 3), bx0, by0);
-            }
-        } else {
-            // ---- spread-out wave: every lane walks the superblocks of its own window, ring by
-            // ring around its own superblock (the wave shares only the loop counters) ----
-            const int lx0 = max(q.qx - R, 0) >> 6, ly0 = max(q.qy - R, 0) >> 6;
-            const int lx1 = min(q.qx + R, (int)a.wa - 1) >> 6, ly1 = min(q.qy + R, (int)a.ha - 1) >> 6;
-            const int scx = q.qx >> 6, scy = q.qy >> 6;
-            for (int ring = 0, t = 0;; ++t) {
+                    cand = (((uint64_t)m_hi << 32) | m_lo) & ~window_le_mask(bx0, by0, cbx, cby, 3);
+                ox = bx0;
+                oy = by0;
+            } else if (mode == 2) {
+                // ---- spread-out wave: every lane walks the superblocks of its own window, ring
+                // by ring around its own superblock (the wave shares only the loop counters) ----
+                ++rt;
                 const int n_in_ring = ring == 0 ? 1 : 8 * ring;
-                if (t >= n_in_ring) {
-                    t = 0;
+                if (rt >= n_in_ring) {
+                    rt = 0;
                     ++ring;
                 }
                 // a superblock of ring r lies at least 64 (r - 1) + 1 rings away
                 const int lb = ring == 0 ? 0 : 64 * (ring - 1) + 1;
-                if (!__builtin_amdgcn_ballot_w64(q.limit != 0u && lb < (int)q.limit))
-                    break;
+                if (!__builtin_amdgcn_ballot_w64(q.limit != 0u && lb < (int)q.limit)) {
+                    mode = 3;
+                    continue;
+                }
                 int dx = 0, dy = 0;
                 if (ring > 0) {
-                    const int side = t / (2 * ring), o = t - side * 2 * ring;
+                    const int side = rt / (2 * ring), o = rt - side * 2 * ring;
                     dx = side == 0 ? -ring + o : side == 1 ? ring : side == 2 ? ring - o : -ring;
                     dy = side == 0 ? -ring : side == 1 ? -ring + o : side == 2 ? ring : ring - o;
                 }
@@ -882,26 +848,174 @@ __global__ __launch_bounds__(256) void ring_list_kernel(ListArgs a)
                 const bool want = inwin && dS < q.limit && box_meets(sb.x, sb.y, q.lo, q.hi);
                 if constexpr (STATS)
                     n_tests += inwin;
-                if (!want)
-                    continue;
-                if constexpr (STATS)
-                    ++n_super;
-                const int bx0 = sx * 8, by0 = sy * 8;
-                uint32_t m_lo = 0, m_hi = 0;
-                const uint2 *win = BBf + (size_t)(by0 + kPadB) * a.bwp + (size_t)(bx0 + kPadB);
+                if (want) {
+                    if constexpr (STATS)
+                        ++n_super;
+                    const int bx0 = sx * 8, by0 = sy * 8;
+                    uint32_t m_lo = 0, m_hi = 0;
+                    const uint2 *win = BBf + (size_t)(by0 + kPadB) * a.bwp + (size_t)(bx0 + kPadB);
 #pragma unroll 1
-                for (int row = 7; row >= 4; --row) {
-                    const ulonglong2 *rp4 = reinterpret_cast<const ulonglong2 *>(win + (size_t)row * a.bwp);
-                    m_hi = test_row_v(m_hi, rp4[0], rp4[1], rp4[2], rp4[3], kq);
-                }
+                    for (int row = 7; row >= 4; --row) {
+                        const ulonglong2 *rp4 = reinterpret_cast<const ulonglong2 *>(win + (size_t)row * a.bwp);
+                        m_hi = test_row_v(m_hi, rp4[0], rp4[1], rp4[2], rp4[3], kq);
+                    }
 #pragma unroll 1
-                for (int row = 3; row >= 0; --row) {
-                    const ulonglong2 *rp4 = reinterpret_cast<const ulonglong2 *>(win + (size_t)row * a.bwp);
-                    m_lo = test_row_v(m_lo, rp4[0], rp4[1], rp4[2], rp4[3], kq);
+                    for (int row = 3; row >= 0; --row) {
+                        const ulonglong2 *rp4 = reinterpret_cast<const ulonglong2 *>(win + (size_t)row * a.bwp);
+                        m_lo = test_row_v(m_lo, rp4[0], rp4[1], rp4[2], rp4[3], kq);
+                    }
+                    if constexpr (STATS)
+                        n_tests += 64u;
+                    cand = (((uint64_t)m_hi << 32) | m_lo) & ~window_le_mask(bx0, by0, cbx, cby, 3);
+                    ox = bx0;
+                    oy = by0;
                 }
-                if constexpr (STATS)
-                    n_tests += 64u;
-                probe_candidates((((uint64_t)m_hi << 32) | m_lo) & ~window_le_mask(bx0, by0, cbx, cby, 3), bx0, by0);
+            }
+            // ---- the window's candidates become tasks (the own window block-ring by block-ring,
+            // nearest first); the pool is executed whenever it holds enough of them ----
+            for (int ps = 0; ps < rounds; ++ps) {
+                uint64_t cur = cand;
+                if (mode == 0) {
+                    cur = cand & kNearLe[ps] & ~(ps ? kNearLe[ps - 1] : 0ull);
+                    if (8 * (ps - 1) + 1 >= (int)q.limit)
+                        cur = 0ull;
+                }
+                // before the own-window results are judged, and at the end, nothing may stay pooled
+                const bool drain = mode == 3 || (mode == 0 && ps == 3);
+                for (;;) {
+                    const bool more = __builtin_amdgcn_ballot_w64(cur != 0ull) != 0ull;
+                    if (more && n_pool <= kListPoolCap - 64u) {
+                        // every lane with a candidate left queues its next one
+                        bool ok = false;
+                        uint32_t task = 0;
+                        if (cur != 0ull) {
+                            const int k = __builtin_ctzll(cur);
+                            cur &= cur - 1ull;
+                            const int bx = ox + (k & 7), by = oy + (k >> 3);
+                            // (the dmin test also keeps stale bounds of unpacked rows from being probed)
+                            ok = (uint32_t)square_dmin(bx * 8 - q.qx, by * 8 - q.qy, 8) < q.limit;
+                            task = lane | ((uint32_t)bx << 6) | ((uint32_t)by << 19);
+                        }
+                        const unsigned long long okm = __builtin_amdgcn_ballot_w64(ok);
+                        if (ok)
+                            s_task[wv][n_pool + __builtin_amdgcn_mbcnt_hi((uint32_t)(okm >> 32),
+                                                                           __builtin_amdgcn_mbcnt_lo((uint32_t)okm, 0u))] = task;
+                        n_pool += (uint32_t)__builtin_popcountll(okm);
+                        continue;
+                    }
+                    if (n_pool > kListPoolCap - 64u || (!more && (n_pool >= kListFlushMin || (drain && n_pool != 0u)))) {
+                        // ---- the pooled tasks, 64 at a time.  Lane i of a go takes task i: query
+                        // box, centre, best key and limit from LDS, the probe like the query's own
+                        // lane would run it, an improvement merged back by minimum -- the tasks of
+                        // one go see the same snapshot of their queries.  (No fence or wave barrier:
+                        // the LDS operations of a wave complete in program order, and either
+                        // intrinsic would turn the scalar loads of the bound rows into vector loads.)
+                        s_best[wv][lane] = q.best; // what the lane knows of its own query
+                        s_lim[wv][lane] = q.limit;
+                        for (uint32_t base = 0; base < n_pool; base += 64u) {
+                            const uint32_t ti = base + lane;
+                            if (ti < n_pool) {
+                                const uint32_t t = s_task[wv][ti], src = t & 63u;
+                                const int bx = (int)((t >> 6) & 0x1FFFu), by = (int)(t >> 19);
+                                LaneQ tq;
+                                const uint2 box = s_box[wv][src], xy = s_qxy[wv][src];
+                                tq.lo = box.x;
+                                tq.hi = box.y;
+                                tq.qx = (int)xy.x;
+                                tq.qy = (int)xy.y;
+                                tq.best = s_best[wv][src];
+                                tq.limit = s_lim[wv][src];
+                                const int x0 = bx * 8 - tq.qx, y0 = by * 8 - tq.qy;
+                                if ((uint32_t)square_dmin(x0, y0, 8) < tq.limit) {
+                                    const uint32_t boff = tf + ((uint32_t)by * a.bw + (uint32_t)bx) * 64u;
+                                    const uint32_t best_before = tq.best;
+                                    const uint32_t nl = probe_block(tq, x0, y0, pb, a.T + boff, a.TT + boff,
+                                                                    reinterpret_cast<const uint32_t *>(a.LB) + (boff >> 1));
+                                    if (tq.best < best_before) {
+                                        atomicMin(&s_best[wv][src], tq.best);
+                                        atomicMin(&s_lim[wv][src], tq.limit);
+                                    }
+                                    if constexpr (STATS) {
+                                        ++n_probed;
+                                        n_tests += 8u * nl;
+                                    }
+                                }
+                            }
+                        }
+                        n_pool = 0u;
+                        if (q.limit != 0u) {
+                            q.best = s_best[wv][lane];
+                            q.limit = s_lim[wv][lane];
+                        }
+                    }
+                    if (!more)
+                        break;
+                }
+            }
+            if (mode == 3)
+                break;
+            if (mode == 0) {
+                // settled: best ring <= 24, or nothing beyond ring 24 to search
+                if (q.limit != 0u && (s_end <= 25u || (q.best != kTileNoKey && (q.best >> ring_shift) <= 24u)))
+                    q.limit = 0u;
+                if (!__builtin_amdgcn_ballot_w64(q.limit != 0u))
+                    break;
+                // ---- far phase: one window for the wave if the lanes still searching lie close
+                // enough together for the 10 x 12 slots, else per-lane windows ----
+                const bool far = q.limit != 0u;
+                wx_lo = (int)wave_min_dpp(far ? (uint32_t)q.qx : 0x7fffffffu);
+                wy_lo = (int)wave_min_dpp(far ? (uint32_t)q.qy : 0x7fffffffu);
+                wx_hi = (int)wave_max_dpp(far ? (uint32_t)q.qx : 0u);
+                wy_hi = (int)wave_max_dpp(far ? (uint32_t)q.qy : 0u);
+                sx0 = max(wx_lo - R, 0) >> 6;
+                sy0 = max(wy_lo - R, 0) >> 6;
+                const int sx1 = min(wx_hi + R, (int)a.wa - 1) >> 6, sy1 = min(wy_hi + R, (int)a.ha - 1) >> 6;
+                nsx = sx1 - sx0 + 1;
+                nsy = sy1 - sy0 + 1;
+                if (nsx <= 10 && nsy <= 12) {
+                    mode = 1;
+                    // middle of the box orders the visits; a lane's own distance differs by <= tol
+                    mx = (wx_lo + wx_hi) >> 1;
+                    my = (wy_lo + wy_hi) >> 1;
+                    tol = (uint32_t)max(wx_hi - mx, wy_hi - my) + 1u;
+                    for (int ty = 0; ty < nsy; ++ty) {
+                        const int sy = sy0 + ty;
+                        const uint32_t row_dw = reinterpret_cast<const uint32_t *>(SBf + (size_t)sy * a.sbwp + sx0)[lane & 31u];
+                        const int ay = (sy << 6) - q.qy;
+                        const int dsy = max(max(ay, -63 - ay), 0);
+                        for (int tx = 0; tx < nsx; ++tx) { // (lane i holds dword i of the row, see ring_tile_kernel)
+                            const uint32_t bmax = (uint32_t)__builtin_amdgcn_readlane((int)row_dw, 2 * tx);
+                            const uint32_t bmin = (uint32_t)__builtin_amdgcn_readlane((int)row_dw, 2 * tx + 1);
+                            const int ax = ((sx0 + tx) << 6) - q.qx;
+                            const uint32_t dS = (uint32_t)max(max(max(ax, -63 - ax), 0), dsy);
+                            const bool w = dS < q.limit && box_meets(bmax, bmin, q.lo, q.hi);
+                            if constexpr (STATS)
+                                n_tests += q.limit != 0u;
+                            if (__builtin_amdgcn_ballot_w64(w)) {
+                                const int rx = ((sx0 + tx) << 6) - mx, ry = (sy << 6) - my;
+                                const uint32_t dref = (uint32_t)max(max(max(rx, -63 - rx), max(ry, -63 - ry)), 0);
+                                const uint32_t t = (uint32_t)(ty * 16 + tx);
+                                const uint32_t key = (dref << 8) | t;
+                                if (lane == (t & 63u)) {
+                                    if (t < 64u)
+                                        skey0 = key;
+                                    else if (t < 128u)
+                                        skey1 = key;
+                                    else
+                                        skey2 = key;
+                                }
+                            }
+                        }
+                    }
+                } else {
+                    mode = 2;
+                    lx0 = max(q.qx - R, 0) >> 6;
+                    ly0 = max(q.qy - R, 0) >> 6;
+                    lx1 = min(q.qx + R, (int)a.wa - 1) >> 6;
+                    ly1 = min(q.qy + R, (int)a.ha - 1) >> 6;
+                    scx = q.qx >> 6;
+                    scy = q.qy >> 6;
+                }
             }
         }
     }
