@@ -361,19 +361,25 @@ extern "C" int cell_pack_selfcheck(void)
 // ---------------------------------------------------------------------------------------
 // CPU emulation of ring_list_kernel (prepared queries: group lists, tiles > 1x1,
 // stepth_distance_dot_array_batch): the same per-lane headers, the kernel's wave-level control
-// flow mirrored with loops over the `lanes` (16, 32 or 64) queries a wave takes -- the lane's
-// own 7x7 window, then either the wave-shared window of superblocks (visited nearest first
-// from the middle of the wave's centres, with the kernel's tolerance and early exit) or, for a
-// spread-out wave, the lane's own ring walk.  Query k: centre (cx[k], cy[k]), colour what[3k..].
-// Outputs per query: d (distance), found, pos (x, y).  Returns 0, or < 0 where the GPU would fault.
+// flow mirrored with loops over the `lanes` (16, 32 or 64) queries a wave takes -- mode 0 the
+// lane's own 7x7 window block-ring by block-ring, then either mode 1, the wave-shared window of
+// superblocks (visited nearest first from the middle of the wave's centres, with the kernel's
+// tolerance and early exit), or mode 2, the lane's own ring walk for a spread-out wave, and
+// mode 3, the drain.  Candidate blocks become tasks in a wave-level pool (capacity 128) that is
+// executed 64 tasks at a time against a snapshot of the queries, results merged by minimum, once
+// it holds 16 tasks, before it could overflow, before the own-window results are judged and at
+// the end -- like the kernel (kListPoolCap, kListFlushMin).  Query k: centre (cx[k], cy[k]),
+// colour what[3k..].  Outputs per query: d (distance), found, pos (x, y).  Returns 0, or < 0
+// where the GPU would fault.
 // ---------------------------------------------------------------------------------------
 extern "C" int list_emulate(const uint32_t *cx, const uint32_t *cy, const uint8_t *what, uint32_t n,
                             const uint8_t *add, uint32_t wa, uint32_t ha, const uint8_t *prec,
                             uint32_t max_steps_in, uint32_t lanes, uint32_t *d_out, uint8_t *found_out,
-                            uint32_t *pos_out, uint64_t *stats /* [3]: shared far waves, per-lane far waves, probes */)
+                            uint32_t *pos_out, uint64_t *stats /* [4]: shared far waves, per-lane far waves, probes, pool goes */)
 {
     static const uint64_t kNearLe[4] = {0x0000000008000000ull, 0x0000001C1C1C0000ull, 0x00003E3E3E3E3E00ull,
                                         0x007F7F7F7F7F7F7Full};
+    constexpr size_t kCap = 128, kMin = 16;
     if (lanes != 16 && lanes != 32 && lanes != 64)
         return -3;
     const Packed P(add, wa, ha);
@@ -383,14 +389,14 @@ extern "C" int list_emulate(const uint32_t *cx, const uint32_t *cy, const uint8_
     while ((2u * top) >> pb)
         ++pb;
     const uint32_t ring_shift = pb + 2;
-    uint64_t n_shared = 0, n_own = 0, n_probes = 0;
-    int fault = 0;
+    uint64_t n_shared = 0, n_own = 0, n_probes = 0, n_goes = 0;
 
     for (uint32_t w0 = 0; w0 < n; w0 += lanes) {
         const uint32_t nl = std::min(lanes, n - w0);
         LaneQ q[64];
         uint32_t s_end[64];
         int cbx[64], cby[64];
+        bool any = false;
         for (uint32_t l = 0; l < nl; ++l) {
             const uint32_t k = w0 + l;
             q[l].qx = (int)cx[k];
@@ -410,6 +416,7 @@ extern "C" int list_emulate(const uint32_t *cx, const uint32_t *cy, const uint8_
                 else if (s_end[l] > 1)
                     q[l].limit = s_end[l];
             }
+            any |= q[l].limit != 0;
         }
         auto bounds_mask = [&](int l, int bx0, int by0) { // the 64 bound tests of a window
             uint64_t mm = 0;
@@ -421,108 +428,108 @@ extern "C" int list_emulate(const uint32_t *cx, const uint32_t *cy, const uint8_
                 }
             return mm;
         };
-        auto probe_candidates = [&](int l, uint64_t cur, int bx0, int by0) {
-            while (cur) {
-                const int k = __builtin_ctzll(cur);
-                cur &= cur - 1;
-                const int bx = bx0 + (k & 7), by = by0 + (k >> 3);
-                const int x0 = bx * 8 - q[l].qx, y0 = by * 8 - q[l].qy;
-                if ((uint32_t)square_dmin(x0, y0, 8) < q[l].limit) {
-                    if (bx < 0 || by < 0 || bx >= (int)P.bw || by >= (int)P.bh) {
-                        fault = -2; // a padded block got through
-                        return;
+        struct Task {
+            int lane, bx, by;
+        };
+        std::vector<Task> pool;
+        int fault = 0;
+        auto flush = [&]() {
+            for (size_t b = 0; b < pool.size(); b += 64) {
+                ++n_goes;
+                const size_t cnt = std::min<size_t>(64, pool.size() - b);
+                LaneQ res[64];
+                for (size_t i = 0; i < cnt; ++i) {
+                    const Task &t = pool[b + i];
+                    LaneQ tq = q[t.lane];
+                    const int x0 = t.bx * 8 - tq.qx, y0 = t.by * 8 - tq.qy;
+                    if ((uint32_t)square_dmin(x0, y0, 8) < tq.limit) {
+                        if (t.bx < 0 || t.by < 0 || t.bx >= (int)P.bw || t.by >= (int)P.bh) {
+                            fault = -2; // a padded block got through
+                            return;
+                        }
+                        const size_t boff = ((size_t)t.by * P.bw + t.bx) * 64;
+                        probe_block(tq, x0, y0, pb, &P.T[boff], &P.TT[boff], reinterpret_cast<const uint32_t *>(&P.LB[boff / 4]));
+                        ++n_probes;
                     }
-                    const size_t boff = ((size_t)by * P.bw + bx) * 64;
-                    probe_block(q[l], x0, y0, pb, &P.T[boff], &P.TT[boff], reinterpret_cast<const uint32_t *>(&P.LB[boff / 4]));
-                    ++n_probes;
+                    res[i] = tq;
+                }
+                for (size_t i = 0; i < cnt; ++i) {
+                    LaneQ &o = q[pool[b + i].lane];
+                    o.best = std::min(o.best, res[i].best);
+                    o.limit = std::min(o.limit, res[i].limit);
                 }
             }
+            pool.clear();
         };
-        // ---- the lane's own 7x7 window ----
-        for (uint32_t l = 0; l < nl; ++l) {
-            if (q[l].limit == 0)
-                continue;
-            if (cby[l] - 3 + kPadB < 0 || cbx[l] - 3 + kPadB < 0 || cby[l] + 4 + kPadB >= (int)P.bhp + 1 ||
-                cbx[l] + 4 + kPadB >= (int)P.bwp + 1)
-                return -4; // the window would leave the padded bounds
-            const uint64_t cand = bounds_mask((int)l, cbx[l] - 3, cby[l] - 3) & kNearLe[3];
-            for (int ps = 0; ps < 4; ++ps) {
-                if (8 * (ps - 1) + 1 >= (int)q[l].limit)
-                    break;
-                probe_candidates((int)l, cand & kNearLe[ps] & ~(ps ? kNearLe[ps - 1] : 0ull), cbx[l] - 3, cby[l] - 3);
-            }
-            if (s_end[l] <= 25 || (q[l].best != kTileNoKey && (q[l].best >> ring_shift) <= 24))
-                q[l].limit = 0;
-        }
-        // ---- far phase ----
-        bool any_far = false;
-        int wx_lo = 0x7fffffff, wy_lo = 0x7fffffff, wx_hi = 0, wy_hi = 0;
-        for (uint32_t l = 0; l < nl; ++l)
-            if (q[l].limit != 0) {
-                any_far = true;
-                wx_lo = std::min(wx_lo, q[l].qx), wy_lo = std::min(wy_lo, q[l].qy);
-                wx_hi = std::max(wx_hi, q[l].qx), wy_hi = std::max(wy_hi, q[l].qy);
-            }
-        if (any_far) {
+        if (any) {
             const int R = (int)max_steps - 1;
-            const int sx0 = std::max(wx_lo - R, 0) >> 6, sy0 = std::max(wy_lo - R, 0) >> 6;
-            const int sx1 = std::min(wx_hi + R, (int)wa - 1) >> 6, sy1 = std::min(wy_hi + R, (int)ha - 1) >> 6;
-            const int nsx = sx1 - sx0 + 1, nsy = sy1 - sy0 + 1;
-            if (nsx <= 10 && nsy <= 12) {
-                ++n_shared;
-                const int mx = (wx_lo + wx_hi) >> 1, my = (wy_lo + wy_hi) >> 1;
-                const uint32_t tol = (uint32_t)std::max(wx_hi - mx, wy_hi - my) + 1u;
-                std::vector<uint32_t> skeys;
-                for (int ty = 0; ty < nsy; ++ty)
-                    for (int tx = 0; tx < nsx; ++tx) {
-                        const int sx = sx0 + tx, sy = sy0 + ty;
-                        const U2 sb = P.SB[(size_t)sy * P.sbw + sx];
-                        bool anyw = false;
-                        for (uint32_t l = 0; l < nl; ++l) {
-                            const uint32_t dS = (uint32_t)square_dmin((sx << 6) - q[l].qx, (sy << 6) - q[l].qy, 64);
-                            anyw |= dS < q[l].limit && box_meets(sb.x, sb.y, q[l].lo, q[l].hi);
-                        }
-                        if (anyw)
-                            skeys.push_back(((uint32_t)square_dmin((sx << 6) - mx, (sy << 6) - my, 64) << 8) |
-                                            (uint32_t)(ty * 16 + tx));
+            int sx0 = 0, sy0 = 0, mxc = 0, myc = 0, ring = 0, rt = -1;
+            uint32_t tol = 0;
+            std::vector<uint32_t> skeys;
+            for (int mode = 0;;) {
+                uint64_t cand[64] = {0};
+                int ox[64] = {0}, oy[64] = {0};
+                int rounds = 1;
+                if (mode == 0) {
+                    for (uint32_t l = 0; l < nl; ++l) {
+                        if (q[l].limit == 0)
+                            continue;
+                        if (cby[l] - 3 + kPadB < 0 || cbx[l] - 3 + kPadB < 0 || cby[l] + 4 + kPadB >= (int)P.bhp + 1 ||
+                            cbx[l] + 4 + kPadB >= (int)P.bwp + 1)
+                            return -4; // the window would leave the padded bounds
+                        cand[l] = bounds_mask((int)l, cbx[l] - 3, cby[l] - 3) & kNearLe[3];
+                        ox[l] = cbx[l] - 3;
+                        oy[l] = cby[l] - 3;
                     }
-                while (!skeys.empty()) {
+                    rounds = 4;
+                } else if (mode == 1) {
+                    if (skeys.empty()) {
+                        mode = 3;
+                        continue;
+                    }
                     const auto itmin = std::min_element(skeys.begin(), skeys.end());
                     const uint32_t pick = *itmin;
                     uint32_t maxlimit = 0;
                     for (uint32_t l = 0; l < nl; ++l)
                         maxlimit = std::max(maxlimit, q[l].limit);
-                    if ((pick >> 8) >= maxlimit + tol)
-                        break;
+                    if ((pick >> 8) >= maxlimit + tol) {
+                        mode = 3;
+                        continue;
+                    }
                     skeys.erase(itmin);
                     const int sx = sx0 + (int)(pick & 15u), sy = sy0 + (int)((pick >> 4) & 15u);
                     const U2 sb = P.SB[(size_t)sy * P.sbw + sx];
+                    bool anyw = false;
                     for (uint32_t l = 0; l < nl; ++l) {
                         const uint32_t dS = (uint32_t)square_dmin((sx << 6) - q[l].qx, (sy << 6) - q[l].qy, 64);
                         if (!(dS < q[l].limit && box_meets(sb.x, sb.y, q[l].lo, q[l].hi)))
                             continue;
+                        anyw = true;
                         const int bx0 = sx * 8, by0 = sy * 8;
-                        probe_candidates((int)l, bounds_mask((int)l, bx0, by0) & ~window_le_mask(bx0, by0, cbx[l], cby[l], 3),
-                                         bx0, by0);
+                        cand[l] = bounds_mask((int)l, bx0, by0) & ~window_le_mask(bx0, by0, cbx[l], cby[l], 3);
+                        ox[l] = bx0;
+                        oy[l] = by0;
                     }
-                }
-            } else {
-                ++n_own;
-                for (int ring = 0, t = 0;; ++t) {
+                    if (!anyw)
+                        continue;
+                } else if (mode == 2) {
+                    ++rt;
                     const int n_in_ring = ring == 0 ? 1 : 8 * ring;
-                    if (t >= n_in_ring) {
-                        t = 0;
+                    if (rt >= n_in_ring) {
+                        rt = 0;
                         ++ring;
                     }
                     const int lb = ring == 0 ? 0 : 64 * (ring - 1) + 1;
                     bool go = false;
                     for (uint32_t l = 0; l < nl; ++l)
                         go |= q[l].limit != 0 && lb < (int)q[l].limit;
-                    if (!go)
-                        break;
+                    if (!go) {
+                        mode = 3;
+                        continue;
+                    }
                     int dx = 0, dy = 0;
                     if (ring > 0) {
-                        const int side = t / (2 * ring), o = t - side * 2 * ring;
+                        const int side = rt / (2 * ring), o = rt - side * 2 * ring;
                         dx = side == 0 ? -ring + o : side == 1 ? ring : side == 2 ? ring - o : -ring;
                         dy = side == 0 ? -ring : side == 1 ? -ring + o : side == 2 ? ring : ring - o;
                     }
@@ -537,14 +544,94 @@ extern "C" int list_emulate(const uint32_t *cx, const uint32_t *cy, const uint8_
                         if (!(dS < q[l].limit && box_meets(sb.x, sb.y, q[l].lo, q[l].hi)))
                             continue;
                         const int bx0 = sx * 8, by0 = sy * 8;
-                        probe_candidates((int)l, bounds_mask((int)l, bx0, by0) & ~window_le_mask(bx0, by0, cbx[l], cby[l], 3),
-                                         bx0, by0);
+                        cand[l] = bounds_mask((int)l, bx0, by0) & ~window_le_mask(bx0, by0, cbx[l], cby[l], 3);
+                        ox[l] = bx0;
+                        oy[l] = by0;
+                    }
+                }
+                for (int ps = 0; ps < rounds; ++ps) {
+                    uint64_t cur[64];
+                    for (uint32_t l = 0; l < nl; ++l) {
+                        cur[l] = cand[l];
+                        if (mode == 0) {
+                            cur[l] = cand[l] & kNearLe[ps] & ~(ps ? kNearLe[ps - 1] : 0ull);
+                            if (8 * (ps - 1) + 1 >= (int)q[l].limit)
+                                cur[l] = 0;
+                        }
+                    }
+                    const bool drain = mode == 3 || (mode == 0 && ps == 3);
+                    for (;;) {
+                        bool more = false;
+                        for (uint32_t l = 0; l < nl; ++l)
+                            more |= cur[l] != 0;
+                        if (more && pool.size() <= kCap - 64) {
+                            for (uint32_t l = 0; l < nl; ++l) {
+                                if (!cur[l])
+                                    continue;
+                                const int k = __builtin_ctzll(cur[l]);
+                                cur[l] &= cur[l] - 1;
+                                const int bx = ox[l] + (k & 7), by = oy[l] + (k >> 3);
+                                if ((uint32_t)square_dmin(bx * 8 - q[l].qx, by * 8 - q[l].qy, 8) < q[l].limit)
+                                    pool.push_back(Task{(int)l, bx, by});
+                            }
+                            continue;
+                        }
+                        if (pool.size() > kCap - 64 || (!more && (pool.size() >= kMin || (drain && !pool.empty())))) {
+                            flush();
+                            if (fault)
+                                return fault;
+                        }
+                        if (!more)
+                            break;
+                    }
+                }
+                if (mode == 3)
+                    break;
+                if (mode == 0) {
+                    bool any_far = false;
+                    int wx_lo = 0x7fffffff, wy_lo = 0x7fffffff, wx_hi = 0, wy_hi = 0;
+                    for (uint32_t l = 0; l < nl; ++l) {
+                        if (q[l].limit != 0 &&
+                            (s_end[l] <= 25 || (q[l].best != kTileNoKey && (q[l].best >> ring_shift) <= 24)))
+                            q[l].limit = 0;
+                        if (q[l].limit != 0) {
+                            any_far = true;
+                            wx_lo = std::min(wx_lo, q[l].qx), wy_lo = std::min(wy_lo, q[l].qy);
+                            wx_hi = std::max(wx_hi, q[l].qx), wy_hi = std::max(wy_hi, q[l].qy);
+                        }
+                    }
+                    if (!any_far)
+                        break;
+                    sx0 = std::max(wx_lo - R, 0) >> 6;
+                    sy0 = std::max(wy_lo - R, 0) >> 6;
+                    const int sx1 = std::min(wx_hi + R, (int)wa - 1) >> 6, sy1 = std::min(wy_hi + R, (int)ha - 1) >> 6;
+                    const int nsx = sx1 - sx0 + 1, nsy = sy1 - sy0 + 1;
+                    if (nsx <= 10 && nsy <= 12) {
+                        ++n_shared;
+                        mode = 1;
+                        mxc = (wx_lo + wx_hi) >> 1;
+                        myc = (wy_lo + wy_hi) >> 1;
+                        tol = (uint32_t)std::max(wx_hi - mxc, wy_hi - myc) + 1u;
+                        for (int ty = 0; ty < nsy; ++ty)
+                            for (int tx = 0; tx < nsx; ++tx) {
+                                const int sx = sx0 + tx, sy = sy0 + ty;
+                                const U2 sb = P.SB[(size_t)sy * P.sbw + sx];
+                                bool anyw = false;
+                                for (uint32_t l = 0; l < nl; ++l) {
+                                    const uint32_t dS = (uint32_t)square_dmin((sx << 6) - q[l].qx, (sy << 6) - q[l].qy, 64);
+                                    anyw |= dS < q[l].limit && box_meets(sb.x, sb.y, q[l].lo, q[l].hi);
+                                }
+                                if (anyw)
+                                    skeys.push_back(((uint32_t)square_dmin((sx << 6) - mxc, (sy << 6) - myc, 64) << 8) |
+                                                    (uint32_t)(ty * 16 + tx));
+                            }
+                    } else {
+                        ++n_own;
+                        mode = 2;
                     }
                 }
             }
         }
-        if (fault)
-            return fault;
         for (uint32_t l = 0; l < nl; ++l) {
             const uint32_t k = w0 + l;
             const bool fnd = q[l].best != kTileNoKey;
@@ -567,6 +654,7 @@ extern "C" int list_emulate(const uint32_t *cx, const uint32_t *cy, const uint8_
         stats[0] = n_shared;
         stats[1] = n_own;
         stats[2] = n_probes;
+        stats[3] = n_goes;
     }
     return 0;
 }
