@@ -194,7 +194,29 @@ def sad_leg(eng, O, frames_np, prec, d_max, win, reps, dev, label):
     return out
 
 
-def ring_leg(eng, O, frames_np, prec, max_steps, reps, check, dev, label):
+def cpu_band_ms(O, main, add, prec, max_steps, rows=16, best_of=3):
+    """the oracle on a band of `rows` pixel rows in the middle of a frame, one group per pixel:
+    best of `best_of` runs, all cores (dynamic schedule) and the reference's 8 static chunks
+    (src/depth_image.rs:111-112) -> (ms_all, ms_ref8, band pixels).  Whole 4K / 8K frames take
+    minutes on the CPU; the band is the stated sample."""
+    h, w = main.shape[:2]
+    y0 = (h // 2) & ~15
+    ys, xs = np.mgrid[y0:y0 + rows, 0:w]
+    g = np.zeros(rows * w, O.GROUP_DTYPE)
+    g["x"], g["y"], g["w"], g["h"] = xs.ravel(), ys.ravel(), 1, 1
+    g["value"] = main[ys.ravel(), xs.ravel(), :3]
+    best = {}
+    for name, thr in (("all", O.ALLCORES), ("ref8", O.REF8)):
+        t = []
+        for _ in range(best_of):
+            t0 = time.perf_counter()
+            O.match_groups(g, add, max_steps, prec, threads=thr)
+            t.append(time.perf_counter() - t0)
+        best[name] = min(t) * 1e3
+    return best["all"], best["ref8"], rows * w
+
+
+def ring_leg(eng, O, frames_np, prec, max_steps, reps, check, dev, label, heavy_first=False, cpu_rows=True):
     """one batched call per repetition on device-resident frames; -> dict for the JSON line"""
     from stepth_amd.engine import PlaneList
     h, w = frames_np[0][0].shape[:2]
@@ -207,7 +229,7 @@ def ring_leg(eng, O, frames_np, prec, max_steps, reps, check, dev, label):
 
     def call(**kw):
         return eng.depth_from_additional_batch(pm, pa, prec, max_steps=max_steps, outs=po,
-                                               asynchronous=True, **kw)
+                                               asynchronous=True, heavy_first=heavy_first, **kw)
     for _ in range(3):
         call()
     torch.cuda.synchronize()
@@ -238,14 +260,26 @@ def ring_leg(eng, O, frames_np, prec, max_steps, reps, check, dev, label):
     # superblock visits in which no block passed its bound test for any query of the wave
     out["block_probes_without_gain"] = round(raw[7] / max(st["blocks_probed"], 1), 3)
     out["superblock_steps_without_candidate"] = round(raw[6] / max(st["superblock_steps"], 1), 3)
+    if heavy_first:
+        out["launch_order"] = "heavy first (STEPTH_FLAG_HEAVY_FIRST: three small launches estimate and sort the tiles)"
+    if cpu_rows and O is not None:
+        # the CPU rows of BASELINE.md section 3 on a stated sample: 16 pixel rows of frame 0
+        ms_all, ms_ref8, band_px = cpu_band_ms(O, frames_np[0][0], frames_np[0][1], prec, max_steps)
+        out["cpu_ms_16_row_band"] = round(ms_all, 2)
+        out["cpu_ref8_ms_16_row_band"] = round(ms_ref8, 2)
+        out["cpu_mpixels_s"] = round(band_px / ms_all / 1e3, 4)
+        out["cpu_ref8_mpixels_s"] = round(band_px / ms_ref8 / 1e3, 4)
+        out["cpu_sample"] = (f"oracle (C restatement, not the Rust binary) on rows {(h // 2) & ~15}..+16 of frame 0, "
+                             f"{O.usable_cpus()} cores dynamic / 8 static chunks, best of 3")
     if check == "full":
-        depth, _ = eng.depth_from_additional_batch(mains[:1], adds[:1], prec, max_steps=max_steps)
+        depth, _ = eng.depth_from_additional_batch(mains[:1], adds[:1], prec, max_steps=max_steps,
+                                                   heavy_first=heavy_first)
         ref = O.depth_from_additional(frames_np[0][0], frames_np[0][1], prec, max_steps, (1, 1))
         out["parity_frame0_bit_exact"] = bool(np.array_equal(depth[0].cpu().numpy(), ref["depth"]))
         out["reference_probes_per_pixel"] = round(ref["probes"] / (w * h), 1)
     elif check == "sample":
         raw, _ = eng.depth_from_additional_batch(mains[:1], adds[:1], prec, max_steps=max_steps,
-                                                 raw_only=True)
+                                                 raw_only=True, heavy_first=heavy_first)
         ok, ppp = sampled_raw_check(O, raw[0].cpu().numpy(), frames_np[0][0], frames_np[0][1], prec,
                                     max_steps)
         out["parity_20000_sampled_pixels_bit_exact"] = ok
@@ -501,7 +535,7 @@ def main():
                 "parallelism": ((f"interleaved {args.interleave}-row strips" if args.interleave and args.mode == "ring"
                                  else "contiguous row strips, cut points following measured per-rank times"
                                  if balancer is not None else "contiguous row strips")
-                                + f" x{world} + all_reduce(max) + gather of rows to rank 0 (RCCL"
+                                + f" x{world} + all_reduce(max) + gather of rows to rank 0 ({'RCCL' if args.backend == 'nccl' else args.backend}"
                                 + (", overlapped with the next step's kernels)" if not args.no_overlap and not args.interleave else ")")
                                 if world > 1 else "single GPU")
                                + (f"; steps alternate over {n_slots} engines/HIP streams" if n_slots > 1
@@ -543,10 +577,18 @@ def main():
             out["asset_tiled_1080p"] = ring_leg(
                 eng, O, asset_frames(1920, 1080, 8), prec, 128, 5, "full", dev,
                 "8 x 1920x1080 = the reference's assets/main.jpg + additional.jpg mirror-tiled "
-                "(natural image statistics), ring first-hit, max_steps=128")
+                "(natural image statistics), ring first-hit, max_steps=128", heavy_first=True)
+            out["asset_tiled_1080p_image_order"] = ring_leg(
+                eng, O, asset_frames(1920, 1080, 8), prec, 128, 5, "full", dev,
+                "same frames, workgroups in image order (the C-ABI default; round 2's figure)", cpu_rows=False)
             out["asset_tiled_1080p_max255"] = ring_leg(
                 eng, O, asset_frames(1920, 1080, 8), prec, 255, 5, "sample", dev,
-                "same frames, max_steps=255 (the reference's own reach, src/depth_image.rs:119)")
+                "same frames, max_steps=255 (the reference's own reach, src/depth_image.rs:119)",
+                heavy_first=True)
+            out["headline_heavy_first"] = ring_leg(
+                eng, O, frames_np, prec, args.d_max, 5, "full", dev,
+                "the headline frames with STEPTH_FLAG_HEAVY_FIRST: most tiles search far, the device keeps "
+                "image order -- what the flag costs where it cannot help", heavy_first=True, cpu_rows=False)
             f4k = make_frames(3840, 2160, 128, 4, bases=1)
             out["config3_4k_d128"] = ring_leg(
                 eng, O, f4k, prec, 128, 3, "sample", dev,
@@ -599,6 +641,42 @@ def main():
                     out["adaptive_flow"]["parity_frame0_bit_exact"] = bool(
                         np.array_equal(d0[0].cpu().numpy(), ref["depth"]))
                     out["adaptive_flow"]["groups_frame0"] = int(len(g))
+            # -- what a user of the crate gets by default (src/depth_image.rs:101-135): adaptive
+            # groups -> max = 255 -> Gaussian tail, on the reference's own pair mirror-tiled
+            if hasattr(eng, "adaptive_depth_batch") and O is not None:
+                af = asset_frames(1920, 1080, 8)
+                am = [torch.from_numpy(l).to(dev) for l, _ in af]
+                aa = [torch.from_numpy(r).to(dev) for _, r in af]
+                ao = [torch.empty((1080, 1920), dtype=torch.uint8, device=dev) for _ in af]
+
+                def dflow():
+                    eng.adaptive_depth_batch(am, aa, prec, max_steps=255, outs=ao, gaussian_tail=True,
+                                             asynchronous=True)
+                dflow()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(5):
+                    dflow()
+                torch.cuda.synchronize()
+                ddt = (time.perf_counter() - t1) / 5
+                d0, _ = eng.adaptive_depth_batch(am[:1], aa[:1], prec, max_steps=255, gaussian_tail=True)
+                g = O.adaptive_groups(af[0][0], prec)
+                t1 = time.perf_counter()
+                ref = O.depth_from_additional(af[0][0], af[0][1], prec, 255, groups=g)
+                cpu_s = time.perf_counter() - t1
+                want = O.gaussian_same_size(ref["depth"])
+                out["reference_default_flow"] = {
+                    "value": round(8 * 1920 * 1080 / ddt / 1e6, 1), "unit": "Mpixels/s",
+                    "ms_per_call": round(ddt * 1e3, 4),
+                    "workload": "8 x 1920x1080 = the reference's pair mirror-tiled: stepth_adaptive_groups_batch "
+                                "(min 16 splits) -> ring first-hit per group, max_steps 255 -> normalise -> paint -> "
+                                "same-size Gaussian resample (src/depth_image.rs:101-135; grouping and resample "
+                                "parity unpinned, DESIGN.md)",
+                    "groups_frame0": int(len(g)),
+                    "parity_frame0_bit_exact": bool(np.array_equal(d0[0].cpu().numpy(), want)),
+                    "cpu_ms_frame0_match_only": round(cpu_s * 1e3, 1),
+                    "cpu_sample": f"oracle PASS 1 + 2 on the oracle's own groups of frame 0, {O.usable_cpus()} cores"}
+                del am, aa, ao
             # -- host-resident frames through the pipelined host batch (the
             # end-to-end, PCIe-inclusive rate; never `value`)
             n_host = 32

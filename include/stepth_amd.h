@@ -227,7 +227,7 @@ int stepth_depth_from_additional_batch(stepth_engine *engine, uint32_t n_frames,
  *   frame: groups[f] = n_groups[f] stepth_group in DEVICE memory (e.g. straight from
  *   stepth_adaptive_groups_batch: the groups never leave the device), images in device memory
  *   of one shape, ring mode, contiguous row strips (params.row_begin/row_end), flags ASYNC /
- *   RAW_ONLY; max_out as in stepth_depth_from_additional_batch.
+ *   RAW_ONLY / GAUSSIAN_TAIL (full frames); max_out as in stepth_depth_from_additional_batch.
  */
 int stepth_adaptive_groups_batch(stepth_engine *engine, uint32_t n_frames, const stepth_image *mains,
                                  const uint8_t precision[3], uint32_t min_splits,

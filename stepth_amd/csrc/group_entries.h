@@ -160,8 +160,9 @@ int stepth_depth_from_groups_batch(stepth_engine *e, uint32_t n_frames, const st
     if (n_frames == 0 || !mains || !adds || !depths || !groups || !n_groups)
         return fail(e, STEPTH_ERR_BAD_ARG, "empty batch or null pointer");
     const stepth_params p = *pp;
-    if (p.mode != STEPTH_MODE_RING_FIRST_HIT || p.row_block || (p.flags & STEPTH_FLAG_GAUSSIAN_TAIL))
-        return fail(e, STEPTH_ERR_BAD_ARG, "group-list batch: ring mode, contiguous strips, no Gaussian tail");
+    if (p.mode != STEPTH_MODE_RING_FIRST_HIT || p.row_block)
+        return fail(e, STEPTH_ERR_BAD_ARG, "group-list batch: ring mode, contiguous strips");
+    const bool gauss_tail = p.flags & STEPTH_FLAG_GAUSSIAN_TAIL; // src/depth_image.rs:133-134
     TRY(check_frames(e, n_frames, mains, adds, depths));
     const uint32_t H = mains[0].height;
     uint32_t row0 = p.row_begin, row1 = p.row_end;
@@ -169,6 +170,8 @@ int stepth_depth_from_groups_batch(stepth_engine *e, uint32_t n_frames, const st
         row1 = H;
     if (row0 >= row1 || row1 > H)
         return fail(e, STEPTH_ERR_BAD_ARG, "row strip [%u,%u) outside 0..%u", row0, row1, H);
+    if (gauss_tail && ((p.flags & STEPTH_FLAG_RAW_ONLY) || row0 != 0 || row1 != H))
+        return fail(e, STEPTH_ERR_BAD_ARG, "STEPTH_FLAG_GAUSSIAN_TAIL needs full-frame, normalised calls");
     HIP_TRY(e, hipSetDevice(e->device));
     const uint64_t cells = (uint64_t)((adds[0].width + 7u) / 8u) * ((adds[0].height + 7u) / 8u) * 64u;
     const uint32_t chunk = (uint32_t)std::max<uint64_t>(
@@ -186,6 +189,12 @@ int stepth_depth_from_groups_batch(stepth_engine *e, uint32_t n_frames, const st
         }
         TRY(ring_queries_batch(e, nf, mains + f0, adds + f0, p, row0, row1, RowPattern{0u, 1u, 0u}, d_groups, ng,
                                depths + f0, max_out ? max_out + f0 : nullptr, any_zero));
+        if (gauss_tail) { // in place on the painted maps
+            uint8_t *planes[kMaxBatch];
+            for (uint32_t f = 0; f < nf; ++f)
+                planes[f] = static_cast<uint8_t *>(const_cast<void *>(depths[f0 + f].data));
+            TRY(gaussian_device_batch(e, nf, planes, depths[0].stride, mains[0].width, H, planes, depths[0].stride));
+        }
     }
     if (!(p.flags & STEPTH_FLAG_ASYNC) && any_zero && !(p.flags & STEPTH_FLAG_RAW_ONLY))
         return fail(e, STEPTH_ERR_MAX_ZERO, "a frame's distances are all 0; its output is all zero");

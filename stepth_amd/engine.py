@@ -358,7 +358,7 @@ class Engine:
 
     def depth_from_groups_batch(self, mains, additionals, precision, groups, counts, *,
                                 max_steps: int = 255, rows: Optional[Tuple[int, int]] = None,
-                                raw_only: bool = False, outs=None, max_out=None,
+                                raw_only: bool = False, gaussian_tail: bool = False, outs=None, max_out=None,
                                 asynchronous: bool = False):
         """stepth_depth_from_groups_batch: `groups[f]` = CUDA uint8 tensor holding at least
         counts[f] stepth_group records (20 bytes each) of frame f.  Returns (outs, max)."""
@@ -382,7 +382,8 @@ class Engine:
         p.tile_w = p.tile_h = 1
         if rows is not None:
             p.row_begin, p.row_end = rows
-        p.flags = (L.FLAG_ASYNC if asynchronous else 0) | (L.FLAG_RAW_ONLY if raw_only else 0)
+        p.flags = (L.FLAG_ASYNC if asynchronous else 0) | (L.FLAG_RAW_ONLY if raw_only else 0) | \
+            (L.FLAG_GAUSSIAN_TAIL if gaussian_tail else 0)
         gp = (C.c_void_p * n)(*[groups[f].data_ptr() for f in range(n)])
         gn = (C.c_size_t * n)(*[int(c) for c in counts])
         if asynchronous:
@@ -397,7 +398,7 @@ class Engine:
 
     def adaptive_depth_batch(self, mains, additionals, precision, *, max_steps: int = 255,
                              min_splits: int = 16, max_splits: int = 0, outs=None,
-                             asynchronous: bool = False):
+                             gaussian_tail: bool = False, asynchronous: bool = False):
         """The path the way the reference runs it (src/depth_image.rs:101-132) for a batch of
         CUDA frames: adaptive groups (the engine's stand-in for disage) -> ring first hit per
         group -> normalise -> paint; the groups stay in device memory.  Returns (outs, max)."""
@@ -406,7 +407,7 @@ class Engine:
         gb = self._group_buffers
         return self.depth_from_groups_batch(mains, additionals, precision, [gb[f] for f in range(len(mains))],
                                             counts, max_steps=max_steps, outs=outs,
-                                            asynchronous=asynchronous)
+                                            gaussian_tail=gaussian_tail, asynchronous=asynchronous)
 
     def host_array(self, shape) -> np.ndarray:
         """uint8 numpy array in page-locked memory (stepth_host_alloc), freed with the array."""

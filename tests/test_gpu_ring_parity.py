@@ -584,9 +584,10 @@ def _big_frame(w, h):
     return tile(l), tile(r)
 
 
-@pytest.mark.parametrize("w,h,ms", [(3840, 2160, 128), (7680, 4320, 255)])
+@pytest.mark.parametrize("w,h,ms", [(3840, 2160, 128), (7680, 4320, 255), (7680, 4320, 256)])
 def test_full_size_properties_4k_8k(engine, oracle, w, h, ms):
-    """BASELINE configs 3 and 5 (4K d_max=128, 8K d_max=256 -> max_steps 255): 20 000 sampled
+    """BASELINE configs 3 and 5 (4K d_max=128; 8K at the reference's reach 255 and at d_max = max_steps = 256,
+    BASELINE.json's literal figure): 20 000 sampled
     pixels against the oracle, plus size-independent properties of the whole frame --
     determinism, normalise consistency, ring-0 pixels zero, strips (as dealt to 8 ranks) compose
     to the full frame, the search never reports a distance beyond its reach"""
