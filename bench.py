@@ -318,6 +318,15 @@ def main():
                     help="N > 1: finish every step's gather before the next step starts")
     ap.add_argument("--no-balance", action="store_true",
                     help="N > 1: keep equal row strips instead of work-weighted ones")
+    ap.add_argument("--dst", default="frames",
+                    help="N > 1, strips: where the depth rows gather: 'frames' = frame f to rank f %% N, every "
+                         "rank a sink (default: rank 0's N-1 inbound links were the exposed part), or a rank "
+                         "number (gather to that rank)")
+    ap.add_argument("--shard", choices=["strips", "frames"], default="strips",
+                    help="N > 1: what `value` is measured on -- row strips of every frame (north_star's "
+                         "partition, the only one for a single big frame) or whole frames per rank (frame f "
+                         "on rank f %% N: no halo, no all_reduce).  The other split is timed too and "
+                         "reported beside it.")
     ap.add_argument("--backend", default="nccl",
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
                          "the multi-rank path with several ranks on one GPU)")
@@ -345,8 +354,8 @@ def main():
             dist.init_process_group(args.backend)
 
     from stepth_amd import MODE_RING_FIRST_HIT, MODE_SAD_WINDOW, Engine
-    from stepth_amd.sharding import (EngineStripWorker, GatherPipeline, StripBalancer, sharded_depth,
-                                     strip_bounds)
+    from stepth_amd.sharding import (EngineStripWorker, GatherPipeline, StripBalancer, frame_sharded_depth,
+                                     sharded_depth, strip_bounds)
 
     W, H = args.width, args.height
     n_frames = args.fpg * world
@@ -358,7 +367,11 @@ def main():
                   for s in sets_np]
     prec = [args.precision] * 3
 
-    def run_timed(n_slots, steps, warmup):
+    dst = None if world == 1 else (args.dst if args.dst == "frames" else int(args.dst))
+    # whole frames per rank: the rank's own frames of every set, as lists that stay the same
+    own_sets = [[fs[i] for i in range(rank, n_frames, world)] for fs in frame_sets]
+
+    def run_timed(n_slots, steps, warmup, shard="strips"):
         """`steps` timed steps alternating over n_slots engines / HIP streams
         -> (seconds, kernel ms, kernel launches, depth of the last step, max, balancer)"""
         torch.cuda.synchronize()
@@ -382,10 +395,10 @@ def main():
         # (lag 2: a step reads the times of the step before the previous one, which has long
         # finished -- reading the previous step's would stall the host until its kernels end)
         balancer = StripBalancer(H, world, align=8, phase=7, lag=max(2, n_slots)) if world > 1 and not args.interleave \
-            and not args.no_balance else None
+            and not args.no_balance and shard == "strips" else None
         # N > 1: the gather of a step's rows to rank 0 runs behind the following kernels; the
         # outstanding gathers are flushed inside the timed region
-        pipelines = [GatherPipeline() if world > 1 and not args.interleave and not args.no_overlap
+        pipelines = [GatherPipeline() if world > 1 and not args.interleave and not args.no_overlap and shard == "strips"
                      else None for _ in range(n_slots)]
         step_no = [0]
 
@@ -394,8 +407,12 @@ def main():
             frames = frame_sets[step_no[0] % n_sets]
             step_no[0] += 1
 
+            own = own_sets[(step_no[0] - 1) % n_sets]
+
             def run():
-                return sharded_depth(workers[slot], frames, H, W, dst=0 if world > 1 else None,
+                if shard == "frames" and world > 1:  # frame f wholly on rank f % N, maps stay there
+                    return frame_sharded_depth(workers[slot], frames, H, W, own_frames=own)
+                return sharded_depth(workers[slot], frames, H, W, dst=dst,
                                      interleave=args.interleave if args.mode == "ring" else 0,
                                      balancer=balancer, pipeline=pipelines[slot])
             if streams[slot] is None:
@@ -454,13 +471,22 @@ def main():
         return float(t.item()), kms, kl, depth, mx, balancer, engines[0], workers[0], last_set
 
     dt, kms, klaunches, depth, _mx, balancer, eng, worker, last_set = run_timed(
-        max(1, args.streams), args.steps, args.warmup)
+        max(1, args.streams), args.steps, args.warmup, args.shard)
+    other = None
+    if world > 1 and args.mode == "ring":
+        # the other split of the same step, timed the same way, reported beside `value`
+        o_shard = "frames" if args.shard == "strips" else "strips"
+        o_dt, o_kms, o_kl, _d, _m, _b, o_eng, _w, _ls = run_timed(max(1, args.streams), args.steps, args.warmup, o_shard)
+        o_eng.close()
+        other = (o_shard, o_dt, o_kms / max(o_kl, 1))
     eng.use_torch_stream()  # the extra legs below run on the default stream
 
     # items examined per pixel on this rank's strips (data-dependent work), outside the timed region
     probes_pp = None
     if args.mode == "ring":
         r0, r1 = (balancer.bounds if balancer is not None else strip_bounds(H, world))[rank]
+        if world > 1 and args.shard == "frames":
+            r0, r1 = 0, H
         pat = None
         if args.interleave and world > 1:
             r0, r1, pat = 0, H, (args.interleave, world, rank)
@@ -480,6 +506,8 @@ def main():
         strip_rows = balancer.bounds[0] if balancer is not None else strip_bounds(H, world)[0]
         # one launch carries this rank's rows of up to 64 frames of the step (batched entry point)
         frames_per_launch = min(n_frames, 64)
+        if world > 1 and args.shard == "frames":  # whole frames: the rank's own ones in one launch
+            strip_rows, frames_per_launch = (0, H), min(len(own_sets[0]), 64)
         px_launch = (strip_rows[1] - strip_rows[0]) * W * frames_per_launch
         k_avg_ms = kms / max(klaunches, 1)
         achieved = ALGO_BYTES_PER_PIXEL * px_launch / (k_avg_ms * 1e-3) / 1e9 if klaunches else 0.0
@@ -532,11 +560,16 @@ def main():
                 "frames_per_step": n_frames, "width": W, "height": H, "d_max": args.d_max,
                 "mode": args.mode,
                 "frame_sets_cycled": n_sets,
-                "parallelism": ((f"interleaved {args.interleave}-row strips" if args.interleave and args.mode == "ring"
-                                 else "contiguous row strips, cut points following measured per-rank times"
-                                 if balancer is not None else "contiguous row strips")
-                                + f" x{world} + all_reduce(max) + gather of rows to rank 0 ({'RCCL' if args.backend == 'nccl' else args.backend}"
-                                + (", overlapped with the next step's kernels)" if not args.no_overlap and not args.interleave else ")")
+                "parallelism": ((f"whole frames per rank (frame f on rank f % {world}): no halo, no all_reduce, "
+                                  f"the maps stay on their rank ({'RCCL' if args.backend == 'nccl' else args.backend} "
+                                  "only for the barrier)") if world > 1 and args.shard == "frames" else
+                                ((f"interleaved {args.interleave}-row strips" if args.interleave and args.mode == "ring"
+                                  else "contiguous row strips, cut points following measured per-rank times"
+                                  if balancer is not None else "contiguous row strips")
+                                 + f" x{world} + all_reduce(max) + gather of rows "
+                                 + ("(frame f to rank f % N: every rank a sink)" if dst == "frames" else f"to rank {dst}")
+                                 + f" ({'RCCL' if args.backend == 'nccl' else args.backend}"
+                                 + (", overlapped with the next step's kernels)" if not args.no_overlap and not args.interleave else ")"))
                                 if world > 1 else "single GPU")
                                + (f"; steps alternate over {n_slots} engines/HIP streams" if n_slots > 1
                                   else "; one HIP stream"),
@@ -555,6 +588,14 @@ def main():
                         "cpu_baseline.reference_probes_per_pixel",
             },
         }
+        if other is not None:
+            out["frame_split" if other[0] == "frames" else "row_strips"] = {
+                "value": round(px_step * args.steps / other[1] / 1e6, 3), "unit": "Mpixels/s",
+                "ms_per_step": round(other[1] / args.steps * 1e3, 4), "kernel_avg_ms": round(other[2], 4),
+                "workload": "the same steps with " + ("whole frames per rank (frame f on rank f % N; no halo, no "
+                            "all_reduce, no gather: BASELINE config 4's independent pairs)" if other[0] == "frames"
+                            else "row strips of every frame over the ranks (north_star's partition)"),
+                "note": "timed like `value` (barrier + synchronize, max over ranks), a second loop after it"}
         O = None
         if not args.no_cpu_baseline:
             O = load_oracle()

@@ -166,7 +166,8 @@ class GatherPipeline:
     it has enqueued its own PASS 1 of the next step, so the xGMI transfers hide behind ~4 ms of
     kernels instead of stalling every rank at the end of each step.  `flush()` hands out the
     maps of the last call (and must be called before the results are used or the clock is
-    stopped).  Gather-to-root with contiguous strips only."""
+    stopped).  Contiguous strips; gather-to-root (`dst=r`) or every rank a sink (`dst="frames"`:
+    the maps handed out are then the rank's own frames)."""
 
     def __init__(self):
         self._inflight = None  # (work, recv, send, bounds, n, height, width, device)
@@ -174,6 +175,19 @@ class GatherPipeline:
 
     def finish_previous(self) -> None:
         if self._inflight is None:
+            return
+        if self._inflight[0] == "frames":  # dst="frames": one gather per destination rank
+            _tag, works, recv, bounds, n_own, height, width, device = self._inflight
+            self._inflight = None
+            for work, _part in works:
+                work.wait()
+            own = torch.empty((n_own, height, width), dtype=torch.uint8, device=device)
+            if recv is not None:
+                recv = recv.to(device)
+                for r, (a, b) in enumerate(bounds):
+                    if b > a:
+                        own[:, a:b] = recv[r, :, : b - a]
+            self.depth = own
             return
         work, recv, _send, bounds, n, height, width, device = self._inflight
         self._inflight = None
@@ -402,7 +416,8 @@ def sharded_depth(worker: StripWorker, frames: Sequence, height: int, width: int
         strips.append(raw)
         maxes.append(mx)
     use_pipeline = pipeline is not None and world > 1 and isinstance(dst, int) and pattern is None
-    if use_pipeline:
+    use_pipeline_f = pipeline is not None and world > 1 and dst == "frames" and pattern is None
+    if use_pipeline or use_pipeline_f:
         pipeline.finish_previous()  # its transfers ran behind the kernels enqueued above
     if use_balancer:
         balancer.stop()  # PASS 1 plus, on the root, the assembly of the previous step's rows
@@ -473,6 +488,7 @@ def sharded_depth(worker: StripWorker, frames: Sequence, height: int, width: int
         # destination, all ranks' links busy at once instead of rank 0's alone).  Returns this
         # rank's frames rank, rank + world, ... as [n_owned, H, W].
         own = None
+        works, recv_mine = [], None
         for d in range(world):
             idx = list(range(d, n, world))
             if not idx:
@@ -482,6 +498,12 @@ def sharded_depth(worker: StripWorker, frames: Sequence, height: int, width: int
             recv_d = (torch.empty((world, len(idx), rows_max, width), dtype=torch.uint8,
                                   device=torch.device("cpu") if via_host else device)
                       if rank == d else None)
+            if use_pipeline_f:  # only start the gathers; the next call (or flush) assembles
+                works.append((dist.gather(part_c, list(recv_d.unbind(0)) if rank == d else None, dst=d,
+                                          group=group, async_op=True), part_c))
+                if rank == d:
+                    recv_mine = recv_d
+                continue
             dist.gather(part_c, list(recv_d.unbind(0)) if rank == d else None, dst=d, group=group)
             if rank == d:
                 recv_d = recv_d.to(device)
@@ -494,6 +516,9 @@ def sharded_depth(worker: StripWorker, frames: Sequence, height: int, width: int
                     for r, (a, b) in enumerate(bounds):
                         if b > a:
                             own[:, a:b] = recv_d[r, :, : b - a]
+        if use_pipeline_f:
+            pipeline._inflight = ("frames", works, recv_mine, bounds, len(range(rank, n, world)), height, width, device)
+            return pipeline.depth, max_all
         if own is None:
             own = torch.empty((0, height, width), dtype=torch.uint8, device=device)
         return own, max_all
@@ -530,6 +555,71 @@ def sharded_depth(worker: StripWorker, frames: Sequence, height: int, width: int
         if b > a:
             depth[:, a:b] = recv[r, :, : b - a]
     return depth, max_all
+
+
+def frame_sharded_depth(worker: StripWorker, frames: Sequence, height: int, width: int,
+                        group: Optional[dist.ProcessGroup] = None,
+                        device: Optional[torch.device] = None,
+                        sync: Optional[Callable[[], None]] = None,
+                        dst=None, own_frames: Optional[Sequence] = None
+                        ) -> Tuple[Optional[torch.Tensor], torch.Tensor]:
+    """Depth maps of `frames` with WHOLE frames dealt to the ranks: frame f belongs to rank
+    f % world (BASELINE config 4: 64 independent pairs over 8 GPUs).  No halo -- a rank packs
+    only the additional images of its own frames --, no cross-rank max (the max is per frame,
+    src/depth_image.rs:124), no balancer; the only exchange is the optional one of the finished
+    maps: `dst=None` every rank keeps the maps of its own frames (returns [n_owned, H, W],
+    max [n_owned]); `dst=r` gathers all maps to rank r (returns [F, H, W] there, None elsewhere).
+    A single 8K frame cannot be split this way -- row strips (sharded_depth) remain the only
+    option there and stay the default.  `own_frames`: the rank's frames as a list object that
+    stays the same from call to call (EngineStripWorker describes a frame set once per list)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    n = len(frames)
+    idx = list(range(rank, n, world))
+    own = own_frames if own_frames is not None else [frames[i] for i in idx]
+    batched = getattr(worker, "can_batch", lambda: False)() and len(own) > 0 and \
+        hasattr(own[0][0], "is_cuda") and own[0][0].is_cuda and hasattr(worker, "depth_batch")
+    if batched:
+        depth, mx = worker.depth_batch(own)  # PASS 1 -> max -> PASS 2 inside one call
+    else:
+        maps, maxes = [], []
+        for f in own:
+            raw, m = worker.match_strip(f, (0, height))
+            worker.normalise(raw, m)
+            maps.append(raw)
+            maxes.append(m.reshape(1))
+        if device is None and maps:
+            device = maps[0].device
+        depth = torch.stack(maps) if maps else torch.empty((0, height, width), dtype=torch.uint8, device=device)
+        mx = torch.cat(maxes).to(torch.int32) if maxes else torch.empty(0, dtype=torch.int32, device=device)
+    if dst is None or world == 1:
+        return depth, mx
+    if device is None:
+        device = depth.device
+    via_host = dist.get_backend(group) == "gloo" and depth.is_cuda
+    n_max = (n + world - 1) // world
+    send = torch.zeros((n_max, height, width), dtype=torch.uint8, device=device)
+    send[: len(idx)] = depth
+    send_m = torch.zeros(n_max, dtype=torch.int32, device=device)
+    send_m[: len(idx)] = mx
+    if sync:
+        sync()
+    coll_dev = torch.device("cpu") if via_host else device
+    recv = torch.empty((world, n_max, height, width), dtype=torch.uint8, device=coll_dev) if rank == dst else None
+    recv_m = torch.empty((world, n_max), dtype=torch.int32, device=coll_dev) if rank == dst else None
+    dist.gather(send.cpu() if via_host else send, list(recv.unbind(0)) if rank == dst else None, dst=dst, group=group)
+    dist.gather(send_m.cpu() if via_host else send_m, list(recv_m.unbind(0)) if rank == dst else None, dst=dst, group=group)
+    if rank != dst:
+        return None, mx
+    recv, recv_m = recv.to(device), recv_m.to(device)
+    full = torch.empty((n, height, width), dtype=torch.uint8, device=device)
+    full_m = torch.empty(n, dtype=torch.int32, device=device)
+    for r in range(world):
+        k = len(range(r, n, world))
+        if k:
+            full[r::world] = recv[r, :k]
+            full_m[r::world] = recv_m[r, :k]
+    return full, full_m
 
 
 # ---- consumers of a row-sharded depth map (src/depth_image.rs:162-247) ---------------------

@@ -416,3 +416,106 @@ def test_balancer_cut_points_keep_their_phase():
             assert bals[0].bounds[0][0] == 0 and bals[0].bounds[-1][1] == 1080
             assert all(b - a >= 8 for a, b in bals[0].bounds)
             assert all(bals[0].bounds[k][1] == bals[0].bounds[k + 1][0] for k in range(world - 1))
+
+
+def _frame_split_rank(rank, world, port, q, dst):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from stepth_amd import synth
+        from stepth_amd.sharding import frame_sharded_depth
+        frames = [synth.stereo_pair(97, 61, 16, seed=s)[:2] for s in (1, 2, 3, 4, 5)]
+        wk = OracleStripWorker([36] * 3, 64, (1, 1))
+        depth, mx = frame_sharded_depth(wk, frames, 61, 97, dst=dst)
+        q.put((rank, None if depth is None else depth.numpy(), mx.numpy()))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,dst", [(2, None), (3, None), (3, 1)])
+def test_frame_split_whole_frames_per_rank(world, dst):
+    """frame_sharded_depth: frame f wholly on rank f % world (BASELINE config 4's independent
+    pairs): no halo, no cross-rank max; every rank ends up with the oracle's maps of its own
+    frames, or one rank with all of them"""
+    from oracle import oracle as O
+    from stepth_amd import synth
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_frame_split_rank, args=(r, world, port, q, dst)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = {rank: (depth, mx) for rank, depth, mx in [q.get(timeout=180) for _ in range(world)]}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    refs = [O.depth_from_additional(*synth.stereo_pair(97, 61, 16, seed=s)[:2], [36] * 3, 64) for s in (1, 2, 3, 4, 5)]
+    for rank in range(world):
+        depth, mx = results[rank]
+        mine = list(range(rank, 5, world))
+        if dst is None:
+            assert depth.shape[0] == len(mine)
+            for k, f in enumerate(mine):
+                np.testing.assert_array_equal(depth[k], refs[f]["depth"])
+            assert [int(v) for v in mx] == [refs[f]["max"] for f in mine]
+        elif rank == dst:
+            assert depth.shape[0] == 5
+            for f in range(5):
+                np.testing.assert_array_equal(depth[f], refs[f]["depth"])
+            assert [int(v) for v in mx] == [r["max"] for r in refs]
+        else:
+            assert depth is None
+
+
+def _pipelined_frames_rank(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from stepth_amd import synth
+        from stepth_amd.sharding import GatherPipeline, sharded_depth
+        sets = [[synth.stereo_pair(97, 61, 16, seed=10 * k + s)[:2] for s in (1, 2, 3)] for k in range(3)]
+        wk = OracleStripWorker([36] * 3, 64, (1, 1))
+        pipe = GatherPipeline()
+        got = []
+        for frames in sets:
+            depth, mx = sharded_depth(wk, frames, 61, 97, dst="frames", pipeline=pipe)
+            got.append((None if depth is None else depth.numpy().copy(), mx.numpy().copy()))
+        last = pipe.flush()
+        q.put((rank, got, last.numpy()))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_pipelined_gather_with_every_rank_a_sink():
+    """dst="frames" + GatherPipeline: the gathers of a step run behind the next step's PASS 1;
+    a call hands out the rank's own frames of the PREVIOUS call, flush() the last ones"""
+    from oracle import oracle as O
+    from stepth_amd import synth
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pipelined_frames_rank, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    refs = [[O.depth_from_additional(*synth.stereo_pair(97, 61, 16, seed=10 * k + s)[:2], [36] * 3, 64) for s in (1, 2, 3)]
+            for k in range(3)]
+    for rank, got, last in results:
+        mine = list(range(rank, 3, world))
+        for k, (depth, mx) in enumerate(got):
+            assert [int(v) for v in mx] == [r["max"] for r in refs[k]]  # the maxima are this call's
+            if k == 0:
+                assert depth is None
+            else:
+                for j, f in enumerate(mine):
+                    np.testing.assert_array_equal(depth[j], refs[k - 1][f]["depth"])  # maps lag one call
+        for j, f in enumerate(mine):
+            np.testing.assert_array_equal(last[j], refs[2][f]["depth"])

@@ -4,6 +4,10 @@ computes its rows of all of them in one batched call; efficiency = time of 8 ful
 time of the slowest rank's share.  No interconnect is involved (the gather overlaps the next
 step's kernels in the real flow), so this is the compute-balance part of the scaling only.
 
+Whole frames per rank (frame f on rank f % N, `bench.py --shard frames`) need no table: a rank's
+share IS 8 full frames of the undivided step -- no halo rows to pack, no cross-rank max, no
+balancer -- 1.00 by construction, printed below from the same measurement for reference.
+
 Three ways of dealing the rows: equal contiguous strips, contiguous strips whose cut points
 follow the measured times (StripBalancer, with the two-step lag of the real flow), interleaved
 16-row blocks -- each with the SAME frames every step and with `--rotate K` distinct frame sets
@@ -59,6 +63,8 @@ for s in sets:  # warm up buffers
     timed(s, (0, H))
 full = [np.median([timed(s, (0, H)) for _ in range(5)]) for s in sets]
 print(f"8 full frames: {[round(t, 3) for t in full]} ms per frame set")
+print("whole frames per rank (frame f on rank f % N): a rank's share = the 8 full frames above -> 1.000 at any N "
+      "(no halo, no all_reduce; the optional gather of finished maps is the only traffic)")
 print("ranks | frames rotate | equal strips | balanced strips (cut points follow times, lag 2) | interleaved 16-row blocks")
 for n in args.ranks:
     for rot in sorted({1, max(1, args.rotate)}):
