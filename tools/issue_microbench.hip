@@ -39,7 +39,7 @@
     "s_and_b64 %0, %0, %4\n s_ff1_i32_b64 %2, %0\n s_or_b64 %1, %1, %4\n s_bcnt1_i32_b64 %3, %1\n" \
     "s_andn2_b64 %0, %0, %4\n s_ff1_i32_b64 %2, %1\n s_xor_b64 %1, %1, %4\n s_bcnt1_i32_b64 %3, %0\n"
 
-enum Kind { K_VALU, K_SALU, K_MIX, K_SALU64, K_CMP_READLANE, K_MIX_HALF, K_ADD64, K_ADD64_SGPR };
+enum Kind { K_VALU, K_SALU, K_MIX, K_SALU64, K_CMP_READLANE, K_MIX_HALF, K_ADD64, K_ADD64_SGPR, K_SAD_U8, K_QSAD, K_MQSAD, K_PK_ADD_U16 };
 
 template <int KIND>
 __global__ __launch_bounds__(256) void issue_kernel(uint32_t iters, uint32_t *out,
@@ -84,6 +84,40 @@ __global__ __launch_bounds__(256) void issue_kernel(uint32_t iters, uint32_t *ou
                              "v_lshl_add_u64 %6, %9, 0, %6\n v_lshl_add_u64 %7, %9, 0, %7\n"
                              : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3), "+v"(w4), "+v"(w5), "+v"(w6), "+v"(w7)
                              : "v"(wk), "s"(mk));
+        } else if constexpr (KIND == K_SAD_U8) { // v_sad_u8: the windowed-SAD mode's inner instruction
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                asm volatile("v_sad_u8 %0, %0, %8, %0\n v_sad_u8 %1, %1, %8, %1\n v_sad_u8 %2, %2, %8, %2\n"
+                             "v_sad_u8 %3, %3, %8, %3\n v_sad_u8 %4, %4, %8, %4\n v_sad_u8 %5, %5, %8, %5\n"
+                             "v_sad_u8 %6, %6, %8, %6\n v_sad_u8 %7, %7, %8, %7\n"
+                             : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7)
+                             : "v"(va));
+        } else if constexpr (KIND == K_QSAD) { // packed quad SAD: 4 byte-shifted 4-byte SADs per instruction
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                asm volatile("v_qsad_pk_u16_u8 %0, %0, %8, %0\n v_qsad_pk_u16_u8 %1, %1, %8, %1\n"
+                             "v_qsad_pk_u16_u8 %2, %2, %8, %2\n v_qsad_pk_u16_u8 %3, %3, %8, %3\n"
+                             "v_qsad_pk_u16_u8 %4, %4, %8, %4\n v_qsad_pk_u16_u8 %5, %5, %8, %5\n"
+                             "v_qsad_pk_u16_u8 %6, %6, %8, %6\n v_qsad_pk_u16_u8 %7, %7, %8, %7\n"
+                             : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3), "+v"(w4), "+v"(w5), "+v"(w6), "+v"(w7)
+                             : "v"(va));
+        } else if constexpr (KIND == K_MQSAD) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                asm volatile("v_mqsad_pk_u16_u8 %0, %0, %8, %0\n v_mqsad_pk_u16_u8 %1, %1, %8, %1\n"
+                             "v_mqsad_pk_u16_u8 %2, %2, %8, %2\n v_mqsad_pk_u16_u8 %3, %3, %8, %3\n"
+                             "v_mqsad_pk_u16_u8 %4, %4, %8, %4\n v_mqsad_pk_u16_u8 %5, %5, %8, %5\n"
+                             "v_mqsad_pk_u16_u8 %6, %6, %8, %6\n v_mqsad_pk_u16_u8 %7, %7, %8, %7\n"
+                             : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3), "+v"(w4), "+v"(w5), "+v"(w6), "+v"(w7)
+                             : "v"(va));
+        } else if constexpr (KIND == K_PK_ADD_U16) { // two 16-bit adds per instruction
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                asm volatile("v_pk_add_u16 %0, %0, %8\n v_pk_add_u16 %1, %1, %8\n v_pk_add_u16 %2, %2, %8\n"
+                             "v_pk_add_u16 %3, %3, %8\n v_pk_add_u16 %4, %4, %8\n v_pk_add_u16 %5, %5, %8\n"
+                             "v_pk_add_u16 %6, %6, %8\n v_pk_add_u16 %7, %7, %8\n"
+                             : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7)
+                             : "v"(va));
         } else if constexpr (KIND == K_SALU) {
 #pragma unroll
             for (int k = 0; k < 4; ++k)
@@ -205,6 +239,10 @@ int main()
         if (run<K_CMP_READLANE>("cmp+ff1+rdlane", w, 40, 24, cus)) return 1;
         if (run<K_ADD64>("add64", w, 32, 0, cus)) return 1;
         if (run<K_ADD64_SGPR>("add64 sgpr", w, 32, 0, cus)) return 1;
+        if (run<K_SAD_U8>("v_sad_u8", w, 32, 0, cus)) return 1;
+        if (run<K_QSAD>("v_qsad_pk_u16", w, 32, 0, cus)) return 1;
+        if (run<K_MQSAD>("v_mqsad_pk_u16", w, 32, 0, cus)) return 1;
+        if (run<K_PK_ADD_U16>("v_pk_add_u16", w, 32, 0, cus)) return 1;
     }
     return 0;
 }
