@@ -434,10 +434,13 @@ int launch_tile(stepth_engine *e, const RingArgs &ra, uint32_t n_frames)
     }
     {
         KernelTimer t(e); // the dominant kernel (bench.py's roofline leg)
+        // (STEPTH_FLAG_HEAVY_FIRST = natural images: the pooled-probe variant goes with the order)
         if (e->stats_enabled)
-            hipLaunchKernelGGL(ring_tile_kernel<true>, grid, block, 0, e->stream, ta);
+            hipLaunchKernelGGL((ring_tile_kernel<true, false>), grid, block, 0, e->stream, ta);
+        else if (ra.heavy_first)
+            hipLaunchKernelGGL((ring_tile_kernel<false, true>), grid, block, 0, e->stream, ta);
         else
-            hipLaunchKernelGGL(ring_tile_kernel<false>, grid, block, 0, e->stream, ta);
+            hipLaunchKernelGGL((ring_tile_kernel<false, false>), grid, block, 0, e->stream, ta);
     }
     HIP_TRY(e, hipGetLastError());
     return STEPTH_OK;

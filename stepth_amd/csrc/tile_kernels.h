@@ -110,12 +110,33 @@ __device__ __forceinline__ uint32_t wave_max_dpp(uint32_t v)
 #define STEPTH_TICK() 0ull
 #endif
 
+// POOL variant (round 3; natural images, STEPTH_FLAG_HEAVY_FIRST).  The bound tests of a window
+// tell every lane which blocks ITS query must look into; in the plain variant each lane then
+// probes its own blocks, and the wave sits through a ~300-instruction probe whenever ANY lane has
+// one.  On the synthetic frames 46 of 64 lanes have, on natural images 1-2 -- the slowest waves
+// ran ~190 probes back to back, a 0.6 ms chain of dependent loads in a 1.2 ms kernel.  With POOL a
+// candidate (query, block) pair is a TASK in a wave-level pool in LDS; tasks are executed 64 at a
+// time by whichever lanes, against the query's box and limit kept in LDS, and merge into its best
+// key by minimum.  The pool is emptied once it holds kPoolFlushMin tasks (waiting longer lets
+// limits go stale and queues probes a hit has made useless), before it could overflow, before
+// step 0's results are judged and at the end of the search.  Results are unchanged: a block is
+// skipped only if its nearest cell lies at or beyond the query's limit of that moment.  Probe
+// goes per wave: 2.9 -> 1.5 on the reference's pair, 4.1 -> 3.5 on the synthetic frames -- where
+// queueing (~25 instructions per round) costs more than the goes it saves: + 10 % time, hence a
+// variant and not a replacement.
+constexpr uint32_t kPoolCap = 128, kPoolFlushMin = 16;
+
 // <= 80 SGPRs keep 8 workgroups of 256 threads resident per CU (MI355X_MICROARCH.md,
 // "Residency": 800 / (sgprs + 16)); the kernel wants 106, the spills to vector lanes cost less
 // than the eighth wave per SIMD brings (1.28 -> 1.22 ms; 96: 1.23, 64: 1.24)
-template <bool STATS>
+template <bool STATS, bool POOL = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void ring_tile_kernel(TileArgs a)
 {
+    // POOL: per wave the queries as the probe tasks see them, and the task pool
+    __shared__ uint2 s_box[POOL ? 4 : 1][POOL ? 64 : 1];           // colour box {lo, hi}
+    __shared__ uint32_t s_best[POOL ? 4 : 1][POOL ? 64 : 1];       // smallest key so far (merged by minimum)
+    __shared__ uint32_t s_lim[POOL ? 4 : 1][POOL ? 64 : 1];        // its limit
+    __shared__ uint32_t s_task[POOL ? 4 : 1][POOL ? kPoolCap : 1]; // query lane | block x << 6 | block y << 19
     [[maybe_unused]] unsigned long long pc_tests = 0, pc_survey = 0, pc_probe = 0;
     [[maybe_unused]] ProbeCounters pcnt{};
     [[maybe_unused]] const unsigned long long pc_t0 = STEPTH_TICK();
@@ -175,7 +196,67 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void ring
 #if defined(STEPTH_ABLATE) && STEPTH_ABLATE == 3 // tuning build: ring 0 only
     q.limit = 0u;
 #endif
+    [[maybe_unused]] uint32_t n_pool = 0; // POOL: tasks in the pool (wave-uniform)
+    // POOL: executes the pooled tasks, 64 at a time.  Lane i of a go takes task i: it reads the
+    // query (box, best key, limit) from LDS, probes the block like the query's own lane would,
+    // and merges an improvement back by minimum -- the tasks of one go see the same snapshot of
+    // their queries.  The lane's OWN query lives in LDS meanwhile (the registers of the probe are
+    // the kernel's peak; this keeps 8 waves per SIMD) and comes back merged afterwards.  No fence
+    // or wave barrier: the LDS operations of a wave complete in program order, and either
+    // intrinsic would turn the scalar loads of the bound rows into vector loads (the compiler
+    // can no longer prove the tables unmodified -- the same reason keeps every global store at
+    // the kernel's end).
+    [[maybe_unused]] auto flush = [&]() __attribute__((always_inline)) {
+        if constexpr (POOL) {
+            s_best[wv][lane] = q.best; // what the lane found out about its own query meanwhile
+            s_lim[wv][lane] = q.limit;
+            for (uint32_t base = 0; base < n_pool; base += 64u) {
+                const uint32_t ti = base + lane;
+                if (ti < n_pool) {
+                    const uint32_t t = s_task[wv][ti], src = t & 63u;
+                    const int bx = (int)((t >> 6) & 0x1FFFu), by = (int)(t >> 19);
+                    LaneQ tq;
+                    const uint2 box = s_box[wv][src];
+                    tq.lo = box.x;
+                    tq.hi = box.y;
+                    tq.best = s_best[wv][src];
+                    tq.limit = s_lim[wv][src];
+                    tq.qx = CBX * 8 + (int)((wv & 1u) * 4u + ((src >> 2) & 3u));
+                    tq.qy = CBY * 8 + (int)((wv >> 1) * 4u + (src >> 4));
+                    const int x0 = bx * 8 - tq.qx, y0 = by * 8 - tq.qy;
+                    // (the dmin test also keeps stale bounds of unpacked rows from being probed)
+                    if ((uint32_t)square_dmin(x0, y0, 8) < tq.limit) {
+                        const uint32_t boff = tf + ((uint32_t)by * a.bw + (uint32_t)bx) * 64u;
+                        const uint32_t best_before = tq.best;
+                        const uint32_t nl = probe_block(tq, x0, y0, pb, a.T + boff, a.TT + boff,
+                                                        reinterpret_cast<const uint32_t *>(a.LB) + (boff >> 1), &pcnt);
+                        if (tq.best < best_before) {
+                            atomicMin(&s_best[wv][src], tq.best);
+                            atomicMin(&s_lim[wv][src], tq.limit);
+                        }
+                        if constexpr (STATS) {
+                            ++n_probed;
+                            n_tests += 8u * nl;
+                            n_probe_void += tq.best == best_before;
+                        }
+                    }
+                }
+            }
+            n_pool = 0u;
+            uint32_t l2 = lane;
+            asm("" : "+v"(l2)); // (opaque: keeps the compiler from carrying the values across instead)
+            const uint2 box = s_box[wv][l2];
+            q.lo = box.x;
+            q.hi = box.y;
+            q.best = s_best[wv][l2];
+            q.limit = s_lim[wv][l2];
+            q.qx = CBX * 8 + (int)((wv & 1u) * 4u + ((l2 >> 2) & 3u));
+            q.qy = CBY * 8 + (int)((wv >> 1) * 4u + (l2 >> 4));
+        }
+    };
     if (__builtin_amdgcn_ballot_w64(q.limit != 0u)) {
+        if constexpr (POOL)
+            s_box[wv][lane] = make_uint2(q.lo, q.hi);
         // superblock window of the wave (far phase): every lane's window of radius
         // max_steps-1 lies inside it
         const int R = (int)a.max_steps - 1;
@@ -185,7 +266,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void ring
         const int nsx = sx1 - sx0 + 1, nsy = sy1 - sy0 + 1; // <= 10 each for max_steps <= 258
         uint32_t skey0 = kTileNoKey, skey1 = kTileNoKey, skey2 = kTileNoKey; // slot ty*16+tx
 
+        [[maybe_unused]] bool done = false; // POOL: the search is over but for the tasks still pooled
         for (uint32_t it = 0;; ++it) {
+            if constexpr (POOL) {
+                // what is still pooled: before step 0's results are judged, and when the search ends
+                if (n_pool != 0u && (it == 1u || done))
+                    flush();
+                if (done)
+                    break;
+            }
             int bx0, by0, r_lo, r_hi;
             uint64_t allow;
             bool want;
@@ -254,8 +343,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void ring
                 // distance from the middle of the wave's centres, which is within 2 rings of
                 // every lane's own distance: past the largest limit + 2 nothing is left.
                 const uint32_t pick = wave_min_dpp(min(min(skey0, skey1), skey2));
-                if (pick == kTileNoKey || (pick >> 8) >= wave_max_dpp(q.limit) + 2u)
+                if (pick == kTileNoKey || (pick >> 8) >= wave_max_dpp(q.limit) + 2u) {
+                    if constexpr (POOL) {
+                        done = true; // (limits only shrink when the pooled tasks run: the search stays over)
+                        continue;
+                    }
                     break;
+                }
                 skey0 = skey0 == pick ? kTileNoKey : skey0;
                 skey1 = skey1 == pick ? kTileNoKey : skey1;
                 skey2 = skey2 == pick ? kTileNoKey : skey2;
@@ -338,6 +432,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void ring
                     cur = 0ull;
                 if (!__builtin_amdgcn_ballot_w64(cur != 0ull))
                     continue;
+                if constexpr (POOL) {
+                    // the block-ring's candidates become tasks; the pool runs when it holds enough
+                    for (;;) {
+                        const bool more = __builtin_amdgcn_ballot_w64(cur != 0ull) != 0ull;
+                        if (n_pool > kPoolCap - 64u || (!more && n_pool >= kPoolFlushMin))
+                            flush();
+                        if (!more)
+                            break;
+                        bool ok = false; // every lane with a candidate left queues its next one
+                        uint32_t task = 0;
+                        if (cur != 0ull) {
+                            const int k = __builtin_ctzll(cur);
+                            cur &= cur - 1ull;
+                            const int bx = bx0 + (k & 7), by = by0 + (k >> 3);
+                            ok = (uint32_t)square_dmin(bx * 8 - q.qx, by * 8 - q.qy, 8) < q.limit;
+                            task = lane | ((uint32_t)bx << 6) | ((uint32_t)by << 19);
+                        }
+                        const unsigned long long okm = __builtin_amdgcn_ballot_w64(ok);
+                        if (ok)
+                            s_task[wv][n_pool + __builtin_amdgcn_mbcnt_hi((uint32_t)(okm >> 32),
+                                                                           __builtin_amdgcn_mbcnt_lo((uint32_t)okm, 0u))] = task;
+                        n_pool += (uint32_t)__builtin_popcountll(okm);
+                    }
+                    continue;
+                }
                 while (cur != 0ull) {
                     STEPTH_CNT(&pcnt, 0);
                     const int k = __builtin_ctzll(cur);
@@ -372,8 +491,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void ring
     uint32_t d8 = 0;
     if (q.best != kTileNoKey && q.best != 0u)
         d8 = key_distance(q.best, pb) & 0xffu; // `d as u8` wraps (depth_image.rs:121)
-    if (valid)
+    if constexpr (POOL) {
+        // the lane's pixel, worked out again (not carried through the probes in registers)
+        uint32_t l2 = lane;
+        asm("" : "+v"(l2));
+        const uint32_t c2 = l2 >> 2, m2 = l2 & 3u;
+        const uint32_t cx2 = (uint32_t)CBX * 8u + (wv & 1u) * 4u + (c2 & 3u), cy2 = (uint32_t)CBY * 8u + (wv >> 1) * 4u + (c2 >> 2);
+        const uint32_t x2 = 2u * cx2 - 1u + (m2 & 1u), y2 = 2u * cy2 - 1u + (m2 >> 1);
+        if (x2 < a.w && y2 >= a.row0 && y2 < a.row1 && a.rp.owns(y2))
+            a.raw[(size_t)f * a.raw_stride + (size_t)(y2 - a.row0) * a.w + x2] = (uint8_t)d8;
+    } else if (valid) {
         a.raw[(size_t)f * a.raw_stride + (size_t)(y - a.row0) * a.w + x] = (uint8_t)d8;
+    }
     // Most waves find nothing beyond what is already there: a plain read first keeps the
     // same-address atomics (~11 ns each, chip-wide) off the common path.  No workgroup
     // barrier: a wave that is done leaves, whatever its neighbours still have to search.

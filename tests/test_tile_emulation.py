@@ -54,13 +54,18 @@ def emu(tmp_path_factory):
 
 
 def _check(emu, oracle, main, add, prec, ms, rows=None):
+    """both variants of the dense search: every lane probing its own blocks (POOL = false) and
+    the pooled probe tasks (POOL = true: kPoolFlushMin 16, kPoolCap 128)"""
     ref = oracle.depth_from_additional(main[..., :3], add, prec, ms, (1, 1))
-    raw, mx, _ = emu(main, add, prec, ms, rows)
     want = ref["raw"] if rows is None else ref["raw"][rows[0]:rows[1]]
-    bad = np.argwhere(raw != want)
-    assert len(bad) == 0, f"{len(bad)} pixels differ, first at {bad[0]}: {raw[tuple(bad[0])]} vs {want[tuple(bad[0])]}"
-    if rows is None:
-        assert mx == ref["max"]
+    for flush_min in (0, 16):
+        emu.lib.tile_emulate_policy(flush_min, 128)
+        raw, mx, _ = emu(main, add, prec, ms, rows)
+        bad = np.argwhere(raw != want)
+        assert len(bad) == 0, f"policy {flush_min}: {len(bad)} pixels differ, first at {bad[0]}: {raw[tuple(bad[0])]} vs {want[tuple(bad[0])]}"
+        if rows is None:
+            assert mx == ref["max"]
+    emu.lib.tile_emulate_policy(0, 128)
 
 
 def test_asset_pair(emu, oracle, asset):

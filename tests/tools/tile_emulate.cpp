@@ -95,10 +95,23 @@ struct Packed {
     }
 };
 
+// Probe policy of the emulated kernel: g_flush_min == 0 -> ring_tile_kernel<.., POOL = false>,
+// every lane probes its own candidate blocks as it finds them; > 0 -> the POOL variant:
+// candidate (query, block) pairs go into a wave-level task pool that is executed 64 tasks at a
+// time against a snapshot of the queries, results merged by minimum, once it holds g_flush_min
+// tasks, before it could overflow (g_pool_cap), at the end of step 0 and of the search.
+static int g_flush_min = 0, g_pool_cap = 128; // 0: the plain variant; 16 / 128 = kPoolFlushMin / kPoolCap of the POOL variant
+extern "C" void tile_emulate_policy(int flush_min, int pool_cap)
+{
+    g_flush_min = flush_min;
+    g_pool_cap = pool_cap;
+}
+
 extern "C" int tile_emulate(const uint8_t *main_px, uint32_t W, uint32_t H, uint32_t mch,
                             const uint8_t *add, uint32_t wa, uint32_t ha, const uint8_t *prec,
                             uint32_t max_steps_in, uint32_t row0, uint32_t row1, uint8_t *raw,
-                            uint32_t *max_out, uint64_t *stats /* [3]: probes, lines, steps */)
+                            uint32_t *max_out,
+                            uint64_t *stats /* [6]: probes, lines, steps, wave-level probe iterations, push iterations, far waves */)
 {
     const Packed P(add, wa, ha);
     const uint32_t bw = P.bw, bh = P.bh, sbw = P.sbw, bwp = P.bwp;
@@ -113,7 +126,7 @@ extern "C" int tile_emulate(const uint8_t *main_px, uint32_t W, uint32_t H, uint
     const uint32_t cbx_n = ((W >> 1) + 8u) >> 3, cby0 = ((row0 + 1u) >> 1) >> 3;
     const uint32_t cby_n = ((row1 >> 1) >> 3) - cby0 + 1u;
     uint32_t mxd = 0;
-    uint64_t n_probes = 0, n_lines = 0, n_steps = 0;
+    uint64_t n_probes = 0, n_lines = 0, n_steps = 0, n_iters = 0, n_push = 0, n_far = 0;
 
     for (uint32_t cbyi = 0; cbyi < cby_n; ++cbyi)
         for (uint32_t cbxi = 0; cbxi < cbx_n; ++cbxi)
@@ -163,6 +176,42 @@ extern "C" int tile_emulate(const uint8_t *main_px, uint32_t W, uint32_t H, uint
                     if (nsx > 16 || nsy > 12)
                         return -1; // the kernel's slots would not fit
                     std::vector<uint32_t> skeys; // wave-level slots
+                    struct Task {
+                        int lane, bx, by;
+                    };
+                    std::vector<Task> pool;
+                    int fault = 0;
+                    // executes the pooled tasks, 64 at a time: the tasks of one go see the same
+                    // snapshot of their queries, results merge by minimum
+                    auto flush = [&]() {
+                        for (size_t b = 0; b < pool.size(); b += 64) {
+                            ++n_iters;
+                            const size_t n = std::min<size_t>(64, pool.size() - b);
+                            LaneQ res[64];
+                            for (size_t i = 0; i < n; ++i) {
+                                const Task &t = pool[b + i];
+                                LaneQ tq = q[t.lane];
+                                const int x0 = t.bx * 8 - tq.qx, y0 = t.by * 8 - tq.qy;
+                                if ((uint32_t)square_dmin(x0, y0, 8) < tq.limit) {
+                                    if (t.bx < 0 || t.by < 0 || t.bx >= (int)bw || t.by >= (int)bh) {
+                                        fault = -2;
+                                        return;
+                                    }
+                                    const size_t boff = ((size_t)t.by * bw + t.bx) * 64;
+                                    n_lines += probe_block(tq, x0, y0, pb, &T[boff], &TT[boff],
+                                                           reinterpret_cast<const uint32_t *>(&LB[boff / 4]));
+                                    ++n_probes;
+                                }
+                                res[i] = tq;
+                            }
+                            for (size_t i = 0; i < n; ++i) {
+                                LaneQ &o = q[pool[b + i].lane];
+                                o.best = std::min(o.best, res[i].best);
+                                o.limit = std::min(o.limit, res[i].limit);
+                            }
+                        }
+                        pool.clear();
+                    };
                     for (uint32_t it = 0;; ++it) {
                         int bx0, by0, r_lo, r_hi;
                         uint64_t allow;
@@ -177,6 +226,9 @@ extern "C" int tile_emulate(const uint8_t *main_px, uint32_t W, uint32_t H, uint
                                 want[l] = q[l].limit != 0;
                         } else {
                             if (it == 1) {
+                                flush(); // the settle test needs step 0's results
+                                if (fault)
+                                    return fault;
                                 bool left = false;
                                 for (int l = 0; l < 64; ++l) {
                                     if (q[l].limit != 0 &&
@@ -186,6 +238,7 @@ extern "C" int tile_emulate(const uint8_t *main_px, uint32_t W, uint32_t H, uint
                                 }
                                 if (!left)
                                     break;
+                                ++n_far;
                                 for (int ty = 0; ty < nsy; ++ty)
                                     for (int tx = 0; tx < nsx; ++tx) {
                                         const int sx = sx0 + tx, sy = sy0 + ty;
@@ -245,11 +298,47 @@ extern "C" int tile_emulate(const uint8_t *main_px, uint32_t W, uint32_t H, uint
                         uint64_t le_prev = r_lo > 0 ? window_le_mask(bx0, by0, CBX, CBY, r_lo - 1) : 0ull;
                         for (int r = r_lo; r <= r_hi; ++r) {
                             const uint64_t le = window_le_mask(bx0, by0, CBX, CBY, r);
+                            if (g_flush_min > 0) {
+                                uint64_t curs[64];
+                                bool more = false;
+                                for (int l = 0; l < 64; ++l) {
+                                    curs[l] = cand[l] & le & ~le_prev;
+                                    if (8 * (r - 1) + 1 >= (int)q[l].limit)
+                                        curs[l] = 0;
+                                    more |= curs[l] != 0;
+                                }
+                                while (more) { // one push per lane and iteration
+                                    ++n_push;
+                                    if ((int)pool.size() + 64 > g_pool_cap)
+                                        flush();
+                                    more = false;
+                                    for (int l = 0; l < 64; ++l) {
+                                        if (!curs[l])
+                                            continue;
+                                        const int k = __builtin_ctzll(curs[l]);
+                                        curs[l] &= curs[l] - 1;
+                                        more |= curs[l] != 0;
+                                        const int bx = bx0 + (k & 7), by = by0 + (k >> 3);
+                                        if ((uint32_t)square_dmin(bx * 8 - q[l].qx, by * 8 - q[l].qy, 8) < q[l].limit)
+                                            pool.push_back(Task{l, bx, by});
+                                    }
+                                }
+                                if ((int)pool.size() >= g_flush_min)
+                                    flush();
+                                if (fault)
+                                    return fault;
+                                le_prev = le;
+                                continue;
+                            }
+                            uint64_t probed_at = 0; // bit j: some lane probed a block in its j-th pop of the round
                             for (int l = 0; l < 64; ++l) {
                                 uint64_t cur = cand[l] & le & ~le_prev;
                                 if (8 * (r - 1) + 1 >= (int)q[l].limit)
                                     cur = 0;
-                                while (cur) {
+                                for (int j = 0; cur; ++j) {
+                                    if ((uint32_t)square_dmin((bx0 + (__builtin_ctzll(cur) & 7)) * 8 - q[l].qx,
+                                                              (by0 + (__builtin_ctzll(cur) >> 3)) * 8 - q[l].qy, 8) < q[l].limit)
+                                        probed_at |= 1ull << j;
                                     const int k = __builtin_ctzll(cur);
                                     cur &= cur - 1;
                                     const int bx = bx0 + (k & 7), by = by0 + (k >> 3);
@@ -264,9 +353,13 @@ extern "C" int tile_emulate(const uint8_t *main_px, uint32_t W, uint32_t H, uint
                                     }
                                 }
                             }
+                            n_iters += (uint64_t)__builtin_popcountll(probed_at);
                             le_prev = le;
                         }
                     }
+                    flush(); // whatever is still pooled when the search ends
+                    if (fault)
+                        return fault;
                 }
                 for (int l = 0; l < 64; ++l) {
                     uint32_t d8 = 0;
@@ -284,6 +377,9 @@ extern "C" int tile_emulate(const uint8_t *main_px, uint32_t W, uint32_t H, uint
         stats[0] = n_probes;
         stats[1] = n_lines;
         stats[2] = n_steps;
+        stats[3] = n_iters;
+        stats[4] = n_push;
+        stats[5] = n_far;
     }
     return 0;
 }
