@@ -229,6 +229,19 @@ int stepth_depth_from_additional_batch(stepth_engine *engine, uint32_t n_frames,
  *   of one shape, ring mode, contiguous row strips (params.row_begin/row_end), flags ASYNC /
  *   RAW_ONLY / GAUSSIAN_TAIL (full frames); max_out as in stepth_depth_from_additional_batch.
  */
+/*
+ * stepth_adaptive_depth_batch: the two calls above in one -- what DepthImage::
+ * load_depth_from_additional does for a user of the crate (src/depth_image.rs:101-135), for
+ * n_frames device frames: adaptive groups (kept in the engine's own buffers) -> ring first hit per
+ * group -> normalise -> paint [-> Gaussian tail].  Whole frames; flags ASYNC / RAW_ONLY /
+ * GAUSSIAN_TAIL.  The group counts still come back to the host once (they size the launches), but
+ * only after the pack kernels have been enqueued: the device works on while the host waits.
+ * n_groups_out: optional, n_frames counts.  max_out as in stepth_depth_from_additional_batch.
+ */
+int stepth_adaptive_depth_batch(stepth_engine *engine, uint32_t n_frames, const stepth_image *mains,
+                                const stepth_image *additionals, const stepth_params *params,
+                                uint32_t min_splits, uint32_t max_splits, const stepth_image *depths,
+                                uint32_t *max_out, size_t *n_groups_out);
 int stepth_adaptive_groups_batch(stepth_engine *engine, uint32_t n_frames, const stepth_image *mains,
                                  const uint8_t precision[3], uint32_t min_splits,
                                  uint32_t max_splits, stepth_group *const *groups_out,

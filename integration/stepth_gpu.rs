@@ -132,6 +132,10 @@ extern "C" {
     pub fn stepth_depth_from_additional_batch(engine: *mut stepth_engine, n_frames: u32,
         mains: *const stepth_image, additionals: *const stepth_image, params: *const stepth_params,
         depths: *const stepth_image, max_out: *mut u32) -> c_int;
+    pub fn stepth_adaptive_depth_batch(engine: *mut stepth_engine, n_frames: u32,
+        mains: *const stepth_image, additionals: *const stepth_image, params: *const stepth_params,
+        min_splits: u32, max_splits: u32, depths: *const stepth_image, max_out: *mut u32,
+        n_groups_out: *mut usize) -> c_int;
     pub fn stepth_adaptive_groups_batch(engine: *mut stepth_engine, n_frames: u32,
         mains: *const stepth_image, precision: *const u8, min_splits: u32, max_splits: u32,
         groups_out: *const *mut stepth_group, capacity: usize, n_out: *mut usize) -> c_int;

@@ -93,6 +93,8 @@ SYMBOLS = {
     "stepth_depth_from_groups_batch": (C.c_int, [C.c_void_p, C.c_uint32, _P(Image), _P(Image),
                                                  _P(Params), _P(C.c_void_p), _P(C.c_size_t), _P(Image),
                                                  C.c_void_p]),
+    "stepth_adaptive_depth_batch": (C.c_int, [C.c_void_p, C.c_uint32, _P(Image), _P(Image), _P(Params), C.c_uint32,
+                                              C.c_uint32, _P(Image), C.c_void_p, _P(C.c_size_t)]),
     "stepth_host_alloc": (C.c_int, [_P(C.c_void_p), C.c_size_t]),
     "stepth_host_free": (None, [C.c_void_p]),
     "stepth_normalise_rows": (C.c_int, [C.c_void_p, _P(Image), C.c_void_p, C.c_uint32,

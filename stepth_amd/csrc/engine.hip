@@ -448,11 +448,26 @@ int launch_tile(stepth_engine *e, const RingArgs &ra, uint32_t n_frames)
 
 // PASS 1 for prepared queries (group lists, tiles > 1x1, distance_dot_array_batch) on the
 // per-lane kernel (tile_kernels.h: ring_list_kernel); `ra` as for launch_ring with qmode 1.
-int launch_list(stepth_engine *e, const RingArgs &ra, uint32_t n_frames)
+int launch_list(stepth_engine *e, const RingArgs &ra, uint32_t n_frames, const PaintArgs *paint = nullptr)
 {
     if (ra.n == 0)
         return STEPTH_OK;
     ListArgs la{};
+    if (paint) { // the search paints raw values itself (small rectangles; big ones are queued)
+        TRY(reserve(e, e->pending, (size_t)ra.n * n_frames * 4));
+        for (uint32_t f = 0; f < n_frames; ++f) {
+            la.paint_groups[f] = paint->groups_list[f];
+            la.paint_out[f] = paint->out[f];
+        }
+        la.paint_stride = paint->ostride;
+        la.paint_w = paint->w;
+        la.paint_h = paint->h;
+        la.paint_row0 = paint->row_begin;
+        la.paint_row1 = paint->row_end;
+        la.big_count = e->words + kWordCounters; // (zeroed with the other words by the pack kernel)
+        la.big_list = (uint32_t *)e->pending.p;
+        la.big_cap = ra.n;
+    }
     la.T = (const uint32_t *)e->T.p;
     la.TT = (const uint32_t *)e->TT.p;
     la.LB = (const uint2 *)e->LB.p;
@@ -903,7 +918,8 @@ static int ring_queries_batch(stepth_engine *e, uint32_t nf, const stepth_image 
                               const stepth_image *adds, const stepth_params &p, uint32_t row0,
                               uint32_t row1, RowPattern rp, const void *const *d_groups,
                               const uint32_t *n_groups, const stepth_image *depths,
-                              uint32_t *max_out, bool &any_zero);
+                              uint32_t *max_out, bool &any_zero, int (*late_counts)(stepth_engine *, uint32_t, uint32_t *) = nullptr,
+                              uint32_t *late_buf = nullptr);
 
 int stepth_depth_from_additional(stepth_engine *e, const stepth_image *main_im,
                                  const stepth_image *add_im, const stepth_params *pp,
@@ -1312,11 +1328,15 @@ static int batch_sad(stepth_engine *e, uint32_t n_frames, const stepth_image *ma
 // PASS 1 + PASS 2 + paint for the prepared-query modes -- uniform tiles larger than 1x1
 // (d_groups == nullptr) or one group list per frame -- for nf <= kMaxBatch device frames in
 // one set of launches (src/depth_image.rs:104-132 for nf images at once).
+// `late_counts`: the group counts are still on their way from the device (adaptive flow); they
+// are fetched -- the one host synchronisation -- after the pack kernels, which do not need them,
+// have been enqueued, so the device works on while the host waits.
 static int ring_queries_batch(stepth_engine *e, uint32_t nf, const stepth_image *mains,
                               const stepth_image *adds, const stepth_params &p, uint32_t row0,
                               uint32_t row1, RowPattern rp, const void *const *d_groups,
                               const uint32_t *n_groups, const stepth_image *depths,
-                              uint32_t *max_out, bool &any_zero)
+                              uint32_t *max_out, bool &any_zero, int (*late_counts)(stepth_engine *, uint32_t, uint32_t *),
+                              uint32_t *late_buf)
 {
     const uint32_t W = mains[0].width, H = mains[0].height, rows = row1 - row0;
     const bool async = p.flags & STEPTH_FLAG_ASYNC, raw_only = p.flags & STEPTH_FLAG_RAW_ONLY;
@@ -1335,6 +1355,10 @@ static int ring_queries_batch(stepth_engine *e, uint32_t nf, const stepth_image 
         TRY(pack_additional_tiles(e, nf, d_adds, adds[0].stride, adds[0].width, adds[0].height, bw, bh, lo, hi));
     else
         TRY(pack_additional(e, nf, d_adds, adds[0].stride, adds[0].width, adds[0].height, bw, bh, lo, hi));
+    if (late_counts) {
+        TRY(late_counts(e, nf, late_buf));
+        n_groups = late_buf;
+    }
 
     RingArgs ra{};
     ra.T = (const uint32_t *)e->T.p;
@@ -1431,11 +1455,6 @@ static int ring_queries_batch(stepth_engine *e, uint32_t nf, const stepth_image 
         for (uint32_t f = 0; f < nf; ++f)
             e->stats_groups += pr.n[f];
     }
-    if (use_list)
-        TRY(launch_list(e, ra, nf));
-    else
-        TRY(launch_ring(e, ra, 1, nf));
-
     PaintArgs pa{};
     pa.raw = ra.raw;
     pa.raw_stride = (uint32_t)raw_stride;
@@ -1460,6 +1479,22 @@ static int ring_queries_batch(stepth_engine *e, uint32_t nf, const stepth_image 
         }
         hipLaunchKernelGGL(zero_rows_kernel, dim3((uint32_t)std::min<size_t>(((size_t)rows * W + 255) / 256, 512), nf),
                            dim3(256), 0, e->stream, pa);
+    }
+    // group lists on the per-lane search: it paints the raw values itself, PASS 2 follows in place
+    const bool fused_paint = d_groups && use_list;
+    if (use_list)
+        TRY(launch_list(e, ra, nf, fused_paint ? &pa : nullptr));
+    else
+        TRY(launch_ring(e, ra, 1, nf));
+
+    if (fused_paint) {
+        hipLaunchKernelGGL(paint_big_kernel, dim3(64, nf), dim3(256), 0, e->stream, pa,
+                           (const uint32_t *)(e->words + kWordCounters), (const uint32_t *)e->pending.p, n_max);
+        // (with RAW_ONLY the LUT is the identity: the launch only publishes the max)
+        const size_t total16 = raw_only ? 1 : (size_t)rows * ((W + 15) / 16);
+        hipLaunchKernelGGL(lut_rows_kernel, dim3((uint32_t)std::min<size_t>((total16 + 255) / 256, 1024), nf), dim3(256), 0,
+                           e->stream, pa);
+    } else if (d_groups) {
         hipLaunchKernelGGL(paint_list_kernel, dim3((n_max + 15) / 16, nf), dim3(256), 0, e->stream, pa);
     } else {
         pa.tile_w = p.tile_w;

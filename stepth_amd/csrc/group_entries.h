@@ -201,3 +201,70 @@ int stepth_depth_from_groups_batch(stepth_engine *e, uint32_t n_frames, const st
     return STEPTH_OK;
     STEPTH_GUARD_END(e)
 }
+
+// fetches the group counts of the grouping launches above (the flow's one host synchronisation)
+static int fetch_group_counts(stepth_engine *e, uint32_t nf, uint32_t *out)
+{
+    std::vector<uint32_t> cnt((size_t)4 * kGroupCtrPad * nf);
+    HIP_TRY(e, hipMemcpyAsync(cnt.data(), e->group_counters.p, cnt.size() * 4, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    for (uint32_t f = 0; f < nf; ++f)
+        out[f] = cnt[(size_t)4 * kGroupCtrPad * f];
+    return STEPTH_OK;
+}
+
+int stepth_adaptive_depth_batch(stepth_engine *e, uint32_t n_frames, const stepth_image *mains,
+                                const stepth_image *adds, const stepth_params *pp, uint32_t min_splits,
+                                uint32_t max_splits, const stepth_image *depths, uint32_t *max_out,
+                                size_t *n_groups_out)
+{
+    STEPTH_GUARD_BEGIN
+    if (!e)
+        return STEPTH_ERR_BAD_ARG;
+    if (!pp || pp->struct_size != sizeof(stepth_params))
+        return fail(e, STEPTH_ERR_BAD_ARG, "params null or struct_size mismatch");
+    if (n_frames == 0 || !mains || !adds || !depths)
+        return fail(e, STEPTH_ERR_BAD_ARG, "empty batch or null pointer");
+    const stepth_params p = *pp;
+    if (p.mode != STEPTH_MODE_RING_FIRST_HIT || p.row_block || p.row_begin || (p.row_end && p.row_end != mains[0].height))
+        return fail(e, STEPTH_ERR_BAD_ARG, "adaptive depth batch: ring mode, whole frames");
+    const bool gauss_tail = p.flags & STEPTH_FLAG_GAUSSIAN_TAIL; // src/depth_image.rs:133-134
+    if (gauss_tail && (p.flags & STEPTH_FLAG_RAW_ONLY))
+        return fail(e, STEPTH_ERR_BAD_ARG, "STEPTH_FLAG_GAUSSIAN_TAIL needs normalised maps");
+    TRY(check_frames(e, n_frames, mains, adds, depths));
+    const uint32_t W = mains[0].width, H = mains[0].height;
+    HIP_TRY(e, hipSetDevice(e->device));
+    const uint64_t cells = (uint64_t)((adds[0].width + 7u) / 8u) * ((adds[0].height + 7u) / 8u) * 64u;
+    const uint32_t chunk = (uint32_t)std::max<uint64_t>(
+        1, std::min<uint64_t>(kMaxBatch, 0x3FFFFFFFull / std::max<uint64_t>(cells, 1)));
+    bool any_zero = false;
+    for (uint32_t f0 = 0; f0 < n_frames; f0 += chunk) {
+        const uint32_t nf = std::min<uint32_t>(chunk, n_frames - f0);
+        const uint8_t *d_mains[kMaxBatch];
+        const void *d_groups[kMaxBatch];
+        uint32_t ng[kMaxBatch];
+        for (uint32_t f = 0; f < nf; ++f)
+            d_mains[f] = static_cast<const uint8_t *>(mains[f0 + f].data);
+        // src/depth_image.rs:101-110 (the engine's own grouping rule, parity with disage unpinned)
+        TRY(adaptive_groups_device(e, nf, d_mains, mains[0].stride, mains[0].channels, W, H, p.precision,
+                                   min_splits, max_splits, nullptr));
+        for (uint32_t f = 0; f < nf; ++f)
+            d_groups[f] = static_cast<GroupRec *>(e->group_out.p) + (size_t)W * H * f;
+        // :112-132; the counts come back while the pack kernels run
+        TRY(ring_queries_batch(e, nf, mains + f0, adds + f0, p, 0, H, RowPattern{0u, 1u, 0u}, d_groups, ng,
+                               depths + f0, max_out ? max_out + f0 : nullptr, any_zero, fetch_group_counts, ng));
+        if (n_groups_out)
+            for (uint32_t f = 0; f < nf; ++f)
+                n_groups_out[f0 + f] = ng[f];
+        if (gauss_tail) {
+            uint8_t *planes[kMaxBatch];
+            for (uint32_t f = 0; f < nf; ++f)
+                planes[f] = static_cast<uint8_t *>(const_cast<void *>(depths[f0 + f].data));
+            TRY(gaussian_device_batch(e, nf, planes, depths[0].stride, W, H, planes, depths[0].stride));
+        }
+    }
+    if (!(p.flags & STEPTH_FLAG_ASYNC) && any_zero && !(p.flags & STEPTH_FLAG_RAW_ONLY))
+        return fail(e, STEPTH_ERR_MAX_ZERO, "a frame's distances are all 0; its output is all zero");
+    return STEPTH_OK;
+    STEPTH_GUARD_END(e)
+}

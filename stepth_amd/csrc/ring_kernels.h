@@ -1135,6 +1135,62 @@ __global__ __launch_bounds__(256) void paint_list_kernel(PaintArgs a)
     }
 }
 
+// PASS 2 in place on rows the search kernel painted with raw values (group lists on
+// ring_list_kernel): v -> v*255/max through the LUT, 16 bytes per lane where everything is
+// aligned.  src/depth_image.rs:125-129.
+__global__ __launch_bounds__(256) void lut_rows_kernel(PaintArgs a)
+{
+    __shared__ uint8_t lut[256];
+    const uint32_t f = blockIdx.y;
+    build_lut(lut, a.max_word + f, a.identity, a.max_out ? a.max_out + f : nullptr);
+    uint8_t *out = a.out[f];
+    const uint32_t rows = a.row_end - a.row_begin;
+    auto map4 = [&](uint32_t v) {
+        return (uint32_t)lut[v & 0xff] | ((uint32_t)lut[(v >> 8) & 0xff] << 8) | ((uint32_t)lut[(v >> 16) & 0xff] << 16) |
+               ((uint32_t)lut[v >> 24] << 24);
+    };
+    if (((reinterpret_cast<uintptr_t>(out) | a.ostride | a.w) & 15u) == 0) {
+        const uint32_t w16 = a.w >> 4;
+        const size_t total = (size_t)rows * w16;
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+            const uint32_t r = (uint32_t)(i / w16), c = (uint32_t)(i - (size_t)r * w16);
+            uint4 *p = reinterpret_cast<uint4 *>(out + (size_t)(a.row_begin + r) * a.ostride + 16u * c);
+            uint4 v = *p;
+            v.x = map4(v.x);
+            v.y = map4(v.y);
+            v.z = map4(v.z);
+            v.w = map4(v.w);
+            *p = v;
+        }
+        return;
+    }
+    const size_t total = (size_t)rows * a.w;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        uint8_t *p = out + (size_t)(a.row_begin + (uint32_t)(i / a.w)) * a.ostride + (i % a.w);
+        *p = lut[*p];
+    }
+}
+
+// The rectangles too large for the search kernel's own lanes (more than kPaintSmall pixels; the
+// search queued them): raw value, one wave per rectangle.
+constexpr uint32_t kPaintSmall = 64;
+__global__ __launch_bounds__(256) void paint_big_kernel(PaintArgs a, const uint32_t *big_count, const uint32_t *big_list,
+                                                        uint32_t cap)
+{
+    const uint32_t f = blockIdx.y, lane = threadIdx.x & 63u;
+    const uint32_t n = min(big_count[f], cap);
+    for (uint32_t k = blockIdx.x * 4u + (threadIdx.x >> 6); k < n; k += gridDim.x * 4u) {
+        const uint32_t g = big_list[(size_t)f * cap + k];
+        const GroupRec r = reinterpret_cast<const GroupRec *>(a.groups_list[f])[g];
+        const uint8_t v = a.raw[(size_t)f * a.raw_stride + g];
+        const uint32_t w = min(r.w, a.w - r.x), h = min(r.h, a.h - r.y);
+        uint8_t *out = a.out[f] + (size_t)r.y * a.ostride + r.x;
+        for (uint32_t yy = 0; yy < h; ++yy)
+            for (uint32_t xx = lane; xx < w; xx += 64u)
+                out[(size_t)yy * a.ostride + xx] = v;
+    }
+}
+
 // in-place PASS 2 on already painted rows (row-strip sharding, after the cross-rank max)
 struct NormArgs {
     uint8_t *data[kMaxBatch]; // one image (view) per frame, blockIdx.y

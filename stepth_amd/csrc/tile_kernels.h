@@ -763,6 +763,17 @@ struct ListArgs {
     uint8_t *found;        // optional: Some / None
     uint32_t *max_word;
     unsigned long long *stats;
+    // optional (group lists): the search paints its result itself -- the raw value into the
+    // group's rectangle when that holds at most kPaintSmall pixels (the reference's groups hold a
+    // few dozen, src/depth_image.rs:102), else the group is queued for paint_big_kernel; PASS 2
+    // then runs in place over the rows (lut_rows_kernel).  Saves the separate paint launch, whose
+    // byte stores took as long as a fifth of the search.
+    const void *paint_groups[kMaxBatch]; // GroupRec lists, frame f's group = the query's slot
+    uint8_t *paint_out[kMaxBatch];       // nullptr: no painting here
+    size_t paint_stride;
+    uint32_t paint_w, paint_h, paint_row0, paint_row1;
+    uint32_t *big_count, *big_list; // per frame: count, list of `big_cap` slots
+    uint32_t big_cap;
 };
 
 // eight bound tests of one row of blocks held in vector registers, highest column first
@@ -1171,6 +1182,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         }
         if (a.found)
             a.found[o] = fnd ? 1 : 0;
+        if (a.paint_out[0]) { // depth_image.rs:130-132, raw value (PASS 2 follows in place)
+            const GroupRec r = reinterpret_cast<const GroupRec *>(a.paint_groups[f])[o];
+            if (r.y >= a.paint_row0 && r.y < a.paint_row1 && r.x < a.paint_w && r.w != 0u && r.h != 0u) {
+                const uint32_t w = min(r.w, a.paint_w - r.x), h = min(r.h, a.paint_h - r.y);
+                if ((uint64_t)w * h <= kPaintSmall) {
+                    uint8_t *out = a.paint_out[f] + (size_t)r.y * a.paint_stride + r.x;
+                    for (uint32_t yy = 0; yy < h; ++yy)
+                        for (uint32_t xx = 0; xx < w; ++xx)
+                            out[(size_t)yy * a.paint_stride + xx] = (uint8_t)(d & 0xffu);
+                } else {
+                    const uint32_t at = atomicAdd(a.big_count + f, 1u);
+                    if (at < a.big_cap)
+                        a.big_list[(size_t)f * a.big_cap + at] = o;
+                }
+            }
+        }
     }
     const uint32_t wmax = wave_max_dpp(d & 0xffu);
     if (lane == 0 && wmax > __hip_atomic_load(a.max_word + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))

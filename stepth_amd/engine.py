@@ -397,17 +397,49 @@ class Engine:
         return outs, [int(v) for v in mx]
 
     def adaptive_depth_batch(self, mains, additionals, precision, *, max_steps: int = 255,
-                             min_splits: int = 16, max_splits: int = 0, outs=None,
-                             gaussian_tail: bool = False, asynchronous: bool = False):
-        """The path the way the reference runs it (src/depth_image.rs:101-132) for a batch of
+                             min_splits: int = 16, max_splits: int = 0, outs=None, max_out=None,
+                             gaussian_tail: bool = False, asynchronous: bool = False, two_calls: bool = False):
+        """The path the way the reference runs it (src/depth_image.rs:101-135) for a batch of
         CUDA frames: adaptive groups (the engine's stand-in for disage) -> ring first hit per
-        group -> normalise -> paint; the groups stay in device memory.  Returns (outs, max)."""
-        self._group_buffers, counts = self.adaptive_groups_batch(
-            mains, precision, min_splits, max_splits, getattr(self, "_group_buffers", None))
-        gb = self._group_buffers
-        return self.depth_from_groups_batch(mains, additionals, precision, [gb[f] for f in range(len(mains))],
-                                            counts, max_steps=max_steps, outs=outs,
-                                            gaussian_tail=gaussian_tail, asynchronous=asynchronous)
+        group -> normalise -> paint [-> Gaussian tail]; the groups never leave the device.
+        One C call (stepth_adaptive_depth_batch); `two_calls` goes through
+        stepth_adaptive_groups_batch + stepth_depth_from_groups_batch instead (same result).
+        Returns (outs, max); `last_group_counts` holds the frames' group counts."""
+        import torch
+        if two_calls:
+            self._group_buffers, counts = self.adaptive_groups_batch(
+                mains, precision, min_splits, max_splits, getattr(self, "_group_buffers", None))
+            gb = self._group_buffers
+            self.last_group_counts = counts
+            return self.depth_from_groups_batch(mains, additionals, precision, [gb[f] for f in range(len(mains))],
+                                                counts, max_steps=max_steps, outs=outs, max_out=max_out,
+                                                gaussian_tail=gaussian_tail, asynchronous=asynchronous)
+        self._follow(mains.tensors if isinstance(mains, PlaneList) else mains)
+        n = len(mains)
+        if outs is None:
+            outs = [torch.zeros(m.shape[:2], dtype=torch.uint8, device=m.device) for m in mains]
+        mi = mains.images if isinstance(mains, PlaneList) else PlaneList(mains, (3, 4), "main").images
+        ai = additionals.images if isinstance(additionals, PlaneList) else PlaneList(additionals, (3,), "additional").images
+        di = outs.images if isinstance(outs, PlaneList) else PlaneList(outs, (1,), "depth").images
+        p = L.Params()
+        p.struct_size = C.sizeof(L.Params)
+        p.mode = L.MODE_RING_FIRST_HIT
+        p.precision = _u8x3(precision)
+        p.max_steps = max_steps
+        p.tile_w = p.tile_h = 1
+        p.flags = (L.FLAG_ASYNC if asynchronous else 0) | (L.FLAG_GAUSSIAN_TAIL if gaussian_tail else 0)
+        counts = (C.c_size_t * n)()
+        if asynchronous:
+            mptr = max_out.data_ptr() if max_out is not None else None
+            self._check(self._lib.stepth_adaptive_depth_batch(self._h, n, mi, ai, C.byref(p), min_splits, max_splits,
+                                                              di, mptr, counts))
+            self.last_group_counts = [int(c) for c in counts]
+            return outs, None
+        mx = (C.c_uint32 * n)()
+        self._check(self._lib.stepth_adaptive_depth_batch(self._h, n, mi, ai, C.byref(p), min_splits, max_splits, di,
+                                                          C.cast(mx, C.c_void_p), counts))
+        self.last_group_counts = [int(c) for c in counts]
+        return outs, [int(v) for v in mx]
 
     def host_array(self, shape) -> np.ndarray:
         """uint8 numpy array in page-locked memory (stepth_host_alloc), freed with the array."""

@@ -127,11 +127,28 @@ def test_batched_group_flow_matches_oracle(engine, oracle):
         m = oracle.match_groups(sel, r, 64, prec)
         want = oracle.paint(sel, m["raw"], 203, 117)
         assert np.array_equal(outs[f].cpu().numpy()[30:90], want[30:90]), f
-    # the fused helper
-    outs2, mx2 = engine.adaptive_depth_batch(mains[:3], adds[:3], prec, max_steps=64, min_splits=12)
-    for f in range(3):
-        ref = oracle.depth_from_additional(pairs[f][0], pairs[f][1], prec, 64, groups=want_groups[f])
-        assert np.array_equal(outs2[f].cpu().numpy(), ref["depth"]), f
+    # both in one call (stepth_adaptive_depth_batch: the counts come back behind the pack kernels),
+    # with and without the Gaussian tail, and the two-call form of the helper
+    outs2, mx2 = engine.adaptive_depth_batch(mains, adds, prec, max_steps=64, min_splits=12)
+    assert engine.last_group_counts == [int(c) for c in counts]
+    outs3, mx3 = engine.adaptive_depth_batch(mains[:3], adds[:3], prec, max_steps=64, min_splits=12, two_calls=True)
+    outs4, _ = engine.adaptive_depth_batch(mains[:2], adds[:2], prec, max_steps=64, min_splits=12, gaussian_tail=True)
+    for f, (l, r) in enumerate(pairs):
+        ref = oracle.depth_from_additional(l, r, prec, 64, groups=want_groups[f])
+        assert mx2[f] == ref["max"] and np.array_equal(outs2[f].cpu().numpy(), ref["depth"]), f
+        if f < 3:
+            assert mx3[f] == ref["max"] and np.array_equal(outs3[f].cpu().numpy(), ref["depth"]), f
+        if f < 2:
+            assert np.array_equal(outs4[f].cpu().numpy(), oracle.gaussian_same_size(ref["depth"])), f
+    # a list with rectangles too large for the search kernel's own lanes (paint_big_kernel)
+    big = np.zeros(3, oracle.GROUP_DTYPE)
+    big["x"], big["y"], big["w"], big["h"] = [0, 100, 0], [0, 0, 60], [100, 103, 203], [60, 60, 57]
+    big["value"] = [pairs[0][0][10, 10], pairs[0][0][20, 150], pairs[0][0][100, 100]]
+    gd = torch.from_numpy(big.view(np.uint8).reshape(-1, 20).copy()).cuda()
+    outs5, mx5 = engine.depth_from_groups_batch(mains[:1], adds[:1], prec, [gd], [3], max_steps=64)
+    ref = oracle.depth_from_additional(pairs[0][0], pairs[0][1], prec, 64, groups=big)
+    if ref["status"] == 0:
+        assert mx5[0] == ref["max"] and np.array_equal(outs5[0].cpu().numpy(), ref["depth"])
 
 
 @pytest.mark.gpu

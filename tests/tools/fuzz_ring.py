@@ -34,18 +34,19 @@ while time.time() - t0 < budget:
     ref = O.depth_from_additional(l, r, prec, ms, (1, 1))
     try:
         mode = rng.integers(0, 3)
+        hf = bool(rng.integers(0, 2))  # STEPTH_FLAG_HEAVY_FIRST: the pooled-probe variant of the dense search
         if mode == 0:
-            d, mx = eng.depth_from_additional(l, r, prec, max_steps=ms)
+            d, mx = eng.depth_from_additional(l, r, prec, max_steps=ms, heavy_first=hf)
             ok = ref["status"] == 0 and mx == ref["max"] and np.array_equal(d, ref["depth"])
         elif mode == 1:
-            outs, mxs = eng.depth_from_additional_batch([l, l[::-1].copy()], [r, r[::-1].copy()], prec, max_steps=ms, raw_only=True)
+            outs, mxs = eng.depth_from_additional_batch([l, l[::-1].copy()], [r, r[::-1].copy()], prec, max_steps=ms, raw_only=True, heavy_first=hf)
             ref2 = O.depth_from_additional(l[::-1].copy(), r[::-1].copy(), prec, ms, (1, 1))
             ok = np.array_equal(outs[0], ref["raw"]) and np.array_equal(outs[1], ref2["raw"]) and mxs == [ref["max"], ref2["max"]]
         else:
             blk, mod = 2 * int(rng.integers(1, 9)), int(rng.integers(1, 5))
             out = np.zeros(l.shape[:2], np.uint8); mm = []
             for rem in range(mod):
-                _, mx = eng.depth_from_additional(l, r, prec, max_steps=ms, raw_only=True, out=out, row_pattern=(blk, mod, rem)); mm.append(mx)
+                _, mx = eng.depth_from_additional(l, r, prec, max_steps=ms, raw_only=True, out=out, row_pattern=(blk, mod, rem), heavy_first=hf); mm.append(mx)
             ok = np.array_equal(out, ref["raw"]) and max(mm) == ref["max"]
     except MaxZeroError:
         ok = ref["status"] == O.ERR_MAX_ZERO
