@@ -66,6 +66,22 @@ int main() {
         std::vector<uint8_t> back((size_t)W * H);
         (void)hipMemcpy(back.data(), dd[0], back.size(), hipMemcpyDeviceToHost);
         if (counts[0] != ng || bmx[0] != m1 || back != list_depth) { printf("batched group flow != single\n"); return 1; }
+        // the two calls in one (the counts come back behind the pack kernels): same bytes
+        size_t counts2[B];
+        CK(stepth_adaptive_depth_batch(e, B, bm, ba, &p, 16, 0, bd, bmx, counts2));
+        (void)hipMemcpy(back.data(), dd[0], back.size(), hipMemcpyDeviceToHost);
+        if (counts2[0] != ng || bmx[0] != m1 || back != list_depth) { printf("one-call adaptive flow != single\n"); return 1; }
+        // one group per pixel with STEPTH_FLAG_HEAVY_FIRST (pooled-probe variant): same bytes as without
+        {
+            stepth_params hp = p; hp.flags |= STEPTH_FLAG_HEAVY_FIRST;
+            uint32_t m_a[B], m_b[B];
+            CK(stepth_depth_from_additional_batch(e, B, bm, ba, &p, bd, m_a));
+            std::vector<uint8_t> plain((size_t)W * H);
+            (void)hipMemcpy(plain.data(), dd[2], plain.size(), hipMemcpyDeviceToHost);
+            CK(stepth_depth_from_additional_batch(e, B, bm, ba, &hp, bd, m_b));
+            (void)hipMemcpy(back.data(), dd[2], back.size(), hipMemcpyDeviceToHost);
+            if (m_a[2] != m_b[2] || back != plain) { printf("heavy-first != image order\n"); return 1; }
+        }
         // uniform 4x4 tiles, batched == single
         stepth_params tp = p; tp.tile_w = tp.tile_h = 4;
         CK(stepth_depth_from_additional_batch(e, B, bm, ba, &tp, bd, bmx));
@@ -94,6 +110,12 @@ int main() {
     CK(stepth_depth_from_additional(e, &mi[1], &ai[1], &p, nullptr, 0, STEPTH_MEM_HOST, &oi, &m1));
     p.mode = STEPTH_MODE_RING_FIRST_HIT; p.tile_w = 4; p.tile_h = 3;
     CK(stepth_depth_from_additional(e, &mi[1], &ai[1], &p, nullptr, 0, STEPTH_MEM_HOST, &oi, &m1));
+    // the exception guard (no device needed)
+    if (stepth_selftest_exception_guard(e, 0) != STEPTH_ERR_OUT_OF_MEMORY || stepth_selftest_exception_guard(e, 1) != STEPTH_ERR_HIP ||
+        stepth_selftest_exception_guard(e, 2) != STEPTH_ERR_HIP || stepth_selftest_exception_guard(e, 9) != STEPTH_OK) {
+        printf("exception guard\n");
+        return 1;
+    }
     void *pin = nullptr; if (stepth_host_alloc(&pin, 1 << 20)) { printf("host_alloc\n"); return 1; } stepth_host_free(pin);
     (void)hipFree(dg);
     stepth_engine_destroy(e);
