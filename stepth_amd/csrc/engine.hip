@@ -543,8 +543,11 @@ int ensure_spiral(stepth_engine *e, uint32_t max_steps, uint32_t wa, uint32_t ha
     return STEPTH_OK;
 }
 
-// ra.n = queries per frame (QMODE 1: the largest of ra.nq[f])
-int launch_ring(stepth_engine *e, RingArgs &ra, int qmode, uint32_t n_frames = 1)
+// The round-1 search (ring_kernels.h: ring0_kernel -> ring_search_kernel -> ring_finish_kernel, one
+// WAVE per <= 4 queries, a block spiral): everything the lane = query kernels of tile_kernels.h
+// do not take -- searches of more than 265 rings.  ra.n = queries per frame (QMODE 1: the largest
+// of ra.nq[f])
+int launch_legacy_search(stepth_engine *e, RingArgs &ra, int qmode, uint32_t n_frames = 1)
 {
     if (ra.n == 0)
         return STEPTH_OK;
@@ -921,6 +924,265 @@ static int ring_queries_batch(stepth_engine *e, uint32_t nf, const stepth_image 
                               uint32_t *max_out, bool &any_zero, int (*late_counts)(stepth_engine *, uint32_t, uint32_t *) = nullptr,
                               uint32_t *late_buf = nullptr);
 
+// What the three modes of stepth_depth_from_additional share: the validated call, the device
+// views of its images (staged copies for host images), the strip.
+struct SingleCall {
+    stepth_params p;
+    const stepth_image *main_im, *add_im;
+    uint32_t W, H, row0, row1;
+    RowPattern rp;
+    bool async, raw_only;
+    const uint8_t *d_main, *d_add;
+    size_t ms, as, os;
+    uint8_t *d_out;
+    uint32_t *max_out;
+    bool max_published; // a paint kernel already stored the max at max_out
+};
+
+// windowed-SAD mode (not in the reference; sad_kernels.h)
+static int single_sad(stepth_engine *e, SingleCall &c, const stepth_group *groups)
+{
+    const stepth_params &p = c.p;
+    const stepth_image *main_im = c.main_im, *add_im = c.add_im;
+    const uint32_t W = c.W, H = c.H, row0 = c.row0, row1 = c.row1;
+    const RowPattern rp = c.rp;
+    const bool async = c.async, raw_only = c.raw_only;
+    const uint8_t *d_main = c.d_main, *d_add = c.d_add;
+    const size_t ms = c.ms, as = c.as, os = c.os;
+    uint8_t *d_out = c.d_out;
+    uint32_t *max_out = c.max_out;
+    bool &max_published = c.max_published;
+    (void)main_im, (void)add_im, (void)H, (void)rp, (void)d_main, (void)ms, (void)as, (void)raw_only;
+    HIP_TRY(e, hipMemsetAsync(e->words, 0, kWordsBytes, e->stream));
+    if (groups)
+        return fail(e, STEPTH_ERR_BAD_ARG, "SAD mode takes no group list");
+    if (add_im->width != W || add_im->height != H)
+        return fail(e, STEPTH_ERR_SIZE_MISMATCH,
+                    "Sizes don't match: SAD mode needs equal image sizes");
+    if ((p.win & 1u) == 0 || p.win > 15 || p.d_max == 0 || p.d_max > 256)
+        return fail(e, STEPTH_ERR_BAD_ARG, "SAD mode: win must be odd <= 15, d_max in 1..256");
+    const uint32_t rows = row1 - row0;
+    TRY(reserve(e, e->raw, (size_t)W * std::max(rows, 1u)));
+    if (rows) {
+        SadArgs sa{};
+        sa.left[0] = d_main;
+        sa.lstride = ms;
+        sa.lch = main_im->channels;
+        sa.right[0] = d_add;
+        sa.rstride = as;
+        sa.n_frames = 1;
+        sa.w = W;
+        sa.h = H;
+        sa.row0 = row0;
+        sa.row1 = row1;
+        sa.d_max = p.d_max;
+        sa.win = p.win;
+        sa.thr = p.win * p.win * ((uint32_t)p.precision[0] + p.precision[1] + p.precision[2]);
+        sa.raw = static_cast<uint8_t *>(e->raw.p);
+        sa.max_word = e->words;
+        if (sad_has_fast_path(sa.win)) {
+            uint32_t prow = 0;
+            int apron = 0;
+            sad_plane_dims(sa, false, sa.lpitch, prow, apron);
+            TRY(reserve(e, e->sad_left, (size_t)sa.lpitch * prow * 4));
+            sad_plane_dims(sa, true, sa.rpitch, prow, apron);
+            TRY(reserve(e, e->sad_right, (size_t)sa.rpitch * prow * 4));
+            sa.lp = (uint32_t *)e->sad_left.p;
+            sa.rp = (uint32_t *)e->sad_right.p;
+            if (launch_sad_pack(sa, e->stream) != STEPTH_OK)
+                return fail(e, STEPTH_ERR_HIP, "sad_pack launch failed");
+        }
+        {
+            KernelTimer t(e);
+            int s = launch_sad(sa, e->stream);
+            if (s != STEPTH_OK)
+                return fail(e, s, "sad_match launch failed: %s",
+                            hipGetErrorString(hipGetLastError()));
+        }
+        PaintArgs pa{};
+        pa.raw = sa.raw;
+        pa.max_word = e->words;
+        pa.max_out = async ? max_out : nullptr;
+        max_published = async && max_out;
+        pa.identity = raw_only;
+        pa.out[0] = d_out;
+        pa.ostride = os;
+        pa.w = W;
+        pa.h = H;
+        pa.row_begin = row0;
+        pa.row_end = row1;
+        pa.tile_w = pa.tile_h = 1;
+        pa.gx = W;
+        const size_t total = (size_t)rows * W;
+        const uint32_t blocks = (uint32_t)std::min<size_t>((total + 255) / 256, 2048);
+        hipLaunchKernelGGL(paint_tiles_kernel, dim3(blocks), dim3(256), 0, e->stream, pa);
+        HIP_TRY(e, hipGetLastError());
+    }
+    return STEPTH_OK;
+}
+
+// prepared queries (an explicit group list, or uniform tiles larger than one pixel): the same
+// code as a batch of one frame, on the device copies of the images
+static int single_prepared(stepth_engine *e, SingleCall &c, const stepth_group *groups, size_t n_groups,
+                           uint32_t groups_memory)
+{
+    const stepth_params &p = c.p;
+    const stepth_image *main_im = c.main_im, *add_im = c.add_im;
+    const uint32_t W = c.W, H = c.H, row0 = c.row0, row1 = c.row1;
+    const RowPattern rp = c.rp;
+    const bool async = c.async, raw_only = c.raw_only;
+    const uint8_t *d_main = c.d_main, *d_add = c.d_add;
+    const size_t ms = c.ms, as = c.as, os = c.os;
+    uint8_t *d_out = c.d_out;
+    uint32_t *max_out = c.max_out;
+    bool &max_published = c.max_published;
+    (void)main_im, (void)add_im, (void)H, (void)rp, (void)d_main, (void)ms, (void)as, (void)raw_only;
+    // prepared queries (an explicit group list, or uniform tiles larger than one pixel): the
+    // same code as a batch of one frame, on the device copies of the images
+    if (!groups && (p.tile_w == 0 || p.tile_h == 0))
+        return fail(e, STEPTH_ERR_BAD_ARG, "tile size 0");
+    if (!groups && (row0 % p.tile_h != 0 || (row1 % p.tile_h != 0 && row1 != H)))
+        return fail(e, STEPTH_ERR_BAD_ARG, "row strip [%u,%u) not aligned to tile_h %u", row0, row1,
+                    p.tile_h);
+    const void *d_groups = nullptr;
+    uint32_t ng = 0;
+    if (groups) {
+        if (n_groups == 0 || n_groups > 0xFFFFFF00ull)
+            return fail(e, STEPTH_ERR_BAD_ARG, "group list of %zu entries", n_groups);
+        ng = (uint32_t)n_groups;
+        if (groups_memory == STEPTH_MEM_DEVICE) {
+            d_groups = groups;
+        } else {
+            TRY(reserve(e, e->stage_groups, n_groups * sizeof(stepth_group)));
+            HIP_TRY(e, hipMemcpyAsync(e->stage_groups.p, groups, n_groups * sizeof(stepth_group),
+                                      hipMemcpyHostToDevice, e->stream));
+            d_groups = e->stage_groups.p;
+        }
+    }
+    const stepth_image dm{d_main, W, H, main_im->channels, STEPTH_MEM_DEVICE, ms};
+    const stepth_image da{d_add, add_im->width, add_im->height, 3, STEPTH_MEM_DEVICE, as};
+    const stepth_image dd{d_out, W, H, 1, STEPTH_MEM_DEVICE, os};
+    stepth_params ap = p;
+    ap.flags |= STEPTH_FLAG_ASYNC; // this function reads the max back itself
+    bool any_zero = false;
+    TRY(ring_queries_batch(e, 1, &dm, &da, ap, row0, row1, rp, groups ? &d_groups : nullptr, &ng, &dd,
+                           async ? max_out : nullptr, any_zero));
+    max_published = async && max_out && row1 > row0;
+    return STEPTH_OK;
+}
+
+// one group per pixel: the dense lane = query search (tile_kernels.h); beyond 265 rings the
+// round-1 search (launch_legacy_search)
+static int single_dense(stepth_engine *e, SingleCall &c)
+{
+    const stepth_params &p = c.p;
+    const stepth_image *main_im = c.main_im, *add_im = c.add_im;
+    const uint32_t W = c.W, H = c.H, row0 = c.row0, row1 = c.row1;
+    const RowPattern rp = c.rp;
+    const bool async = c.async, raw_only = c.raw_only;
+    const uint8_t *d_main = c.d_main, *d_add = c.d_add;
+    const size_t ms = c.ms, as = c.as, os = c.os;
+    uint8_t *d_out = c.d_out;
+    uint32_t *max_out = c.max_out;
+    bool &max_published = c.max_published;
+    (void)main_im, (void)add_im, (void)H, (void)rp, (void)d_main, (void)ms, (void)as, (void)raw_only;
+    // one group per pixel
+    uint32_t bw = 0, bh = 0;
+    uint32_t lo = 0, hi = 0xFFFFFFFFu;
+    if (p.max_steps < 0x40000000u) {
+        // rows of the additional image the strip's searches can reach: the centres lie in
+        // rows [row0/2, (row1+1)/2], every search stays within max_steps-1 rings of its centre
+        const uint32_t reach = p.max_steps ? p.max_steps - 1u : 0u;
+        const uint32_t c_lo = row0 / 2u, c_hi = (row1 + 1u) / 2u;
+        lo = c_lo > reach ? c_lo - reach : 0u;
+        hi = c_hi + reach + 1u;
+    }
+    // the dense lane = query search (tile_kernels.h); beyond 263 rings the round-1 trio
+    const bool use_tile = tile_search_fits(p.max_steps, add_im->width, add_im->height);
+    if (use_tile)
+        TRY(pack_additional_tiles(e, 1, &d_add, as, add_im->width, add_im->height, bw, bh, lo, hi));
+    else
+        TRY(pack_additional(e, 1, &d_add, as, add_im->width, add_im->height, bw, bh, lo, hi));
+
+    RingArgs ra{};
+    ra.T = (const uint32_t *)e->T.p;
+    ra.BB = (const uint2 *)e->BB.p;
+    ra.SB = (const uint2 *)e->SB.p;
+    ra.sbw = (bw + 7u) / 8u;
+    ra.sbh = (bh + 7u) / 8u;
+    ra.wa = add_im->width;
+    ra.ha = add_im->height;
+    ra.bw = bw;
+    ra.bh = bh;
+    ra.max_steps = p.max_steps;
+    memcpy(ra.prec, p.precision, 3);
+    ra.max_word = e->words;
+    const uint32_t rows = row1 - row0;
+    ra.n = W * rows;
+    ra.main_px[0] = d_main;
+    ra.mstride = ms;
+    ra.mch = main_im->channels;
+    ra.w = W;
+    ra.row0 = row0;
+    ra.row1 = row1;
+    // (round-1 trio) 2x2 tiles anchored at odd coordinates: tile (tx,ty) = pixels 2tx-1..2tx x
+    // 2ty-1..2ty, all of which have middle (tx,ty)
+    ra.ntx = (W >> 1) + 1u;
+    ra.ty0 = (row0 + 1u) >> 1;
+    uint64_t n_slots = rows ? (uint64_t)ra.ntx * ((row1 >> 1) - ra.ty0 + 1u) * 4u : 0u;
+    ra.rp = rp;
+    if (rp.block) {
+        // owned blocks b = rem, rem+mod, ... with b*block < H
+        const uint32_t nb_all = (H + rp.block - 1u) / rp.block;
+        const uint32_t nb = nb_all > rp.rem ? (nb_all - rp.rem + rp.mod - 1u) / rp.mod : 0u;
+        n_slots = rows ? (uint64_t)ra.ntx * nb * (rp.block / 2u + 1u) * 4u : 0u;
+    }
+    if (n_slots > 0xFFFFFFFFull && !use_tile)
+        return fail(e, STEPTH_ERR_BAD_ARG, "%ux%u pixels: too many query slots for one call", W, rows);
+    ra.n_slots = (uint32_t)std::min<uint64_t>(n_slots, 0xFFFFFFFFull);
+    TRY(reserve(e, e->raw, std::max<size_t>(ra.n, 4)));
+    ra.raw = static_cast<uint8_t *>(e->raw.p);
+    if (e->stats_enabled) {
+        HIP_TRY(e, hipMemsetAsync(e->stats, 0, kStatsBytes, e->stream));
+        e->stats_groups = ra.n;
+    }
+    ra.heavy_first = (p.flags & STEPTH_FLAG_HEAVY_FIRST) != 0;
+    if (use_tile)
+        TRY(launch_tile(e, ra, 1));
+    else
+        TRY(launch_legacy_search(e, ra, 0));
+
+    if (rows) {
+        PaintArgs pa{};
+        pa.max_word = e->words;
+        pa.max_out = async ? max_out : nullptr;
+        pa.identity = raw_only;
+        pa.out[0] = d_out;
+        pa.ostride = os;
+        pa.w = W;
+        pa.h = H;
+        pa.row_begin = row0;
+        pa.row_end = row1;
+        pa.rp = rp;
+        pa.tile_w = pa.tile_h = 1;
+        pa.gx = W;
+        pa.raw = ra.raw;
+        pa.n = ra.n;
+        max_published = async && max_out;
+        if ((W & 3u) == 0 && (os & 3u) == 0 && (reinterpret_cast<uintptr_t>(d_out) & 3u) == 0) {
+            const size_t total = (size_t)rows * (W / 4);
+            const uint32_t blocks = (uint32_t)std::min<size_t>((total + 255) / 256, 2048);
+            hipLaunchKernelGGL(paint_1x1_vec4_kernel, dim3(blocks), dim3(256), 0, e->stream, pa);
+        } else {
+            const size_t total = (size_t)rows * W;
+            const uint32_t blocks = (uint32_t)std::min<size_t>((total + 255) / 256, 2048);
+            hipLaunchKernelGGL(paint_tiles_kernel, dim3(blocks), dim3(256), 0, e->stream, pa);
+        }
+        HIP_TRY(e, hipGetLastError());
+    }
+    return STEPTH_OK;
+}
+
 int stepth_depth_from_additional(stepth_engine *e, const stepth_image *main_im,
                                  const stepth_image *add_im, const stepth_params *pp,
                                  const stepth_group *groups, size_t n_groups,
@@ -990,204 +1252,16 @@ int stepth_depth_from_additional(stepth_engine *e, const stepth_image *main_im,
                                         e->stream));
     }
 
-    bool max_published = false; // a paint kernel already stored the max at max_out
-
-    if (p.mode == STEPTH_MODE_SAD_WINDOW) {
-        HIP_TRY(e, hipMemsetAsync(e->words, 0, kWordsBytes, e->stream));
-        if (groups)
-            return fail(e, STEPTH_ERR_BAD_ARG, "SAD mode takes no group list");
-        if (add_im->width != W || add_im->height != H)
-            return fail(e, STEPTH_ERR_SIZE_MISMATCH,
-                        "Sizes don't match: SAD mode needs equal image sizes");
-        if ((p.win & 1u) == 0 || p.win > 15 || p.d_max == 0 || p.d_max > 256)
-            return fail(e, STEPTH_ERR_BAD_ARG, "SAD mode: win must be odd <= 15, d_max in 1..256");
-        const uint32_t rows = row1 - row0;
-        TRY(reserve(e, e->raw, (size_t)W * std::max(rows, 1u)));
-        if (rows) {
-            SadArgs sa{};
-            sa.left[0] = d_main;
-            sa.lstride = ms;
-            sa.lch = main_im->channels;
-            sa.right[0] = d_add;
-            sa.rstride = as;
-            sa.n_frames = 1;
-            sa.w = W;
-            sa.h = H;
-            sa.row0 = row0;
-            sa.row1 = row1;
-            sa.d_max = p.d_max;
-            sa.win = p.win;
-            sa.thr = p.win * p.win * ((uint32_t)p.precision[0] + p.precision[1] + p.precision[2]);
-            sa.raw = static_cast<uint8_t *>(e->raw.p);
-            sa.max_word = e->words;
-            if (sad_has_fast_path(sa.win)) {
-                uint32_t prow = 0;
-                int apron = 0;
-                sad_plane_dims(sa, false, sa.lpitch, prow, apron);
-                TRY(reserve(e, e->sad_left, (size_t)sa.lpitch * prow * 4));
-                sad_plane_dims(sa, true, sa.rpitch, prow, apron);
-                TRY(reserve(e, e->sad_right, (size_t)sa.rpitch * prow * 4));
-                sa.lp = (uint32_t *)e->sad_left.p;
-                sa.rp = (uint32_t *)e->sad_right.p;
-                if (launch_sad_pack(sa, e->stream) != STEPTH_OK)
-                    return fail(e, STEPTH_ERR_HIP, "sad_pack launch failed");
-            }
-            {
-                KernelTimer t(e);
-                int s = launch_sad(sa, e->stream);
-                if (s != STEPTH_OK)
-                    return fail(e, s, "sad_match launch failed: %s",
-                                hipGetErrorString(hipGetLastError()));
-            }
-            PaintArgs pa{};
-            pa.raw = sa.raw;
-            pa.max_word = e->words;
-            pa.max_out = async ? max_out : nullptr;
-            max_published = async && max_out;
-            pa.identity = raw_only;
-            pa.out[0] = d_out;
-            pa.ostride = os;
-            pa.w = W;
-            pa.h = H;
-            pa.row_begin = row0;
-            pa.row_end = row1;
-            pa.tile_w = pa.tile_h = 1;
-            pa.gx = W;
-            const size_t total = (size_t)rows * W;
-            const uint32_t blocks = (uint32_t)std::min<size_t>((total + 255) / 256, 2048);
-            hipLaunchKernelGGL(paint_tiles_kernel, dim3(blocks), dim3(256), 0, e->stream, pa);
-            HIP_TRY(e, hipGetLastError());
-        }
-    } else if (p.mode == STEPTH_MODE_RING_FIRST_HIT && (groups || p.tile_w != 1 || p.tile_h != 1)) {
-        // prepared queries (an explicit group list, or uniform tiles larger than one pixel): the
-        // same code as a batch of one frame, on the device copies of the images
-        if (!groups && (p.tile_w == 0 || p.tile_h == 0))
-            return fail(e, STEPTH_ERR_BAD_ARG, "tile size 0");
-        if (!groups && (row0 % p.tile_h != 0 || (row1 % p.tile_h != 0 && row1 != H)))
-            return fail(e, STEPTH_ERR_BAD_ARG, "row strip [%u,%u) not aligned to tile_h %u", row0, row1,
-                        p.tile_h);
-        const void *d_groups = nullptr;
-        uint32_t ng = 0;
-        if (groups) {
-            if (n_groups == 0 || n_groups > 0xFFFFFF00ull)
-                return fail(e, STEPTH_ERR_BAD_ARG, "group list of %zu entries", n_groups);
-            ng = (uint32_t)n_groups;
-            if (groups_memory == STEPTH_MEM_DEVICE) {
-                d_groups = groups;
-            } else {
-                TRY(reserve(e, e->stage_groups, n_groups * sizeof(stepth_group)));
-                HIP_TRY(e, hipMemcpyAsync(e->stage_groups.p, groups, n_groups * sizeof(stepth_group),
-                                          hipMemcpyHostToDevice, e->stream));
-                d_groups = e->stage_groups.p;
-            }
-        }
-        const stepth_image dm{d_main, W, H, main_im->channels, STEPTH_MEM_DEVICE, ms};
-        const stepth_image da{d_add, add_im->width, add_im->height, 3, STEPTH_MEM_DEVICE, as};
-        const stepth_image dd{d_out, W, H, 1, STEPTH_MEM_DEVICE, os};
-        stepth_params ap = p;
-        ap.flags |= STEPTH_FLAG_ASYNC; // this function reads the max back itself
-        bool any_zero = false;
-        TRY(ring_queries_batch(e, 1, &dm, &da, ap, row0, row1, rp, groups ? &d_groups : nullptr, &ng, &dd,
-                               async ? max_out : nullptr, any_zero));
-        max_published = async && max_out && row1 > row0;
-    } else if (p.mode == STEPTH_MODE_RING_FIRST_HIT) {
-        // one group per pixel
-        uint32_t bw = 0, bh = 0;
-        uint32_t lo = 0, hi = 0xFFFFFFFFu;
-        if (p.max_steps < 0x40000000u) {
-            // rows of the additional image the strip's searches can reach: the centres lie in
-            // rows [row0/2, (row1+1)/2], every search stays within max_steps-1 rings of its centre
-            const uint32_t reach = p.max_steps ? p.max_steps - 1u : 0u;
-            const uint32_t c_lo = row0 / 2u, c_hi = (row1 + 1u) / 2u;
-            lo = c_lo > reach ? c_lo - reach : 0u;
-            hi = c_hi + reach + 1u;
-        }
-        // the dense lane = query search (tile_kernels.h); beyond 263 rings the round-1 trio
-        const bool use_tile = tile_search_fits(p.max_steps, add_im->width, add_im->height);
-        if (use_tile)
-            TRY(pack_additional_tiles(e, 1, &d_add, as, add_im->width, add_im->height, bw, bh, lo, hi));
-        else
-            TRY(pack_additional(e, 1, &d_add, as, add_im->width, add_im->height, bw, bh, lo, hi));
-
-        RingArgs ra{};
-        ra.T = (const uint32_t *)e->T.p;
-        ra.BB = (const uint2 *)e->BB.p;
-        ra.SB = (const uint2 *)e->SB.p;
-        ra.sbw = (bw + 7u) / 8u;
-        ra.sbh = (bh + 7u) / 8u;
-        ra.wa = add_im->width;
-        ra.ha = add_im->height;
-        ra.bw = bw;
-        ra.bh = bh;
-        ra.max_steps = p.max_steps;
-        memcpy(ra.prec, p.precision, 3);
-        ra.max_word = e->words;
-        const uint32_t rows = row1 - row0;
-        ra.n = W * rows;
-        ra.main_px[0] = d_main;
-        ra.mstride = ms;
-        ra.mch = main_im->channels;
-        ra.w = W;
-        ra.row0 = row0;
-        ra.row1 = row1;
-        // (round-1 trio) 2x2 tiles anchored at odd coordinates: tile (tx,ty) = pixels 2tx-1..2tx x
-        // 2ty-1..2ty, all of which have middle (tx,ty)
-        ra.ntx = (W >> 1) + 1u;
-        ra.ty0 = (row0 + 1u) >> 1;
-        uint64_t n_slots = rows ? (uint64_t)ra.ntx * ((row1 >> 1) - ra.ty0 + 1u) * 4u : 0u;
-        ra.rp = rp;
-        if (rp.block) {
-            // owned blocks b = rem, rem+mod, ... with b*block < H
-            const uint32_t nb_all = (H + rp.block - 1u) / rp.block;
-            const uint32_t nb = nb_all > rp.rem ? (nb_all - rp.rem + rp.mod - 1u) / rp.mod : 0u;
-            n_slots = rows ? (uint64_t)ra.ntx * nb * (rp.block / 2u + 1u) * 4u : 0u;
-        }
-        if (n_slots > 0xFFFFFFFFull && !use_tile)
-            return fail(e, STEPTH_ERR_BAD_ARG, "%ux%u pixels: too many query slots for one call", W, rows);
-        ra.n_slots = (uint32_t)std::min<uint64_t>(n_slots, 0xFFFFFFFFull);
-        TRY(reserve(e, e->raw, std::max<size_t>(ra.n, 4)));
-        ra.raw = static_cast<uint8_t *>(e->raw.p);
-        if (e->stats_enabled) {
-            HIP_TRY(e, hipMemsetAsync(e->stats, 0, kStatsBytes, e->stream));
-            e->stats_groups = ra.n;
-        }
-        ra.heavy_first = (p.flags & STEPTH_FLAG_HEAVY_FIRST) != 0;
-        if (use_tile)
-            TRY(launch_tile(e, ra, 1));
-        else
-            TRY(launch_ring(e, ra, 0));
-
-        if (rows) {
-            PaintArgs pa{};
-            pa.max_word = e->words;
-            pa.max_out = async ? max_out : nullptr;
-            pa.identity = raw_only;
-            pa.out[0] = d_out;
-            pa.ostride = os;
-            pa.w = W;
-            pa.h = H;
-            pa.row_begin = row0;
-            pa.row_end = row1;
-            pa.rp = rp;
-            pa.tile_w = pa.tile_h = 1;
-            pa.gx = W;
-            pa.raw = ra.raw;
-            pa.n = ra.n;
-            max_published = async && max_out;
-            if ((W & 3u) == 0 && (os & 3u) == 0 && (reinterpret_cast<uintptr_t>(d_out) & 3u) == 0) {
-                const size_t total = (size_t)rows * (W / 4);
-                const uint32_t blocks = (uint32_t)std::min<size_t>((total + 255) / 256, 2048);
-                hipLaunchKernelGGL(paint_1x1_vec4_kernel, dim3(blocks), dim3(256), 0, e->stream, pa);
-            } else {
-                const size_t total = (size_t)rows * W;
-                const uint32_t blocks = (uint32_t)std::min<size_t>((total + 255) / 256, 2048);
-                hipLaunchKernelGGL(paint_tiles_kernel, dim3(blocks), dim3(256), 0, e->stream, pa);
-            }
-            HIP_TRY(e, hipGetLastError());
-        }
-    } else {
+    SingleCall c{p, main_im, add_im, W, H, row0, row1, rp, async, raw_only, d_main, d_add, ms, as, os, d_out, max_out, false};
+    if (p.mode == STEPTH_MODE_SAD_WINDOW)
+        TRY(single_sad(e, c, groups));
+    else if (p.mode == STEPTH_MODE_RING_FIRST_HIT && (groups || p.tile_w != 1 || p.tile_h != 1))
+        TRY(single_prepared(e, c, groups, n_groups, groups_memory));
+    else if (p.mode == STEPTH_MODE_RING_FIRST_HIT)
+        TRY(single_dense(e, c));
+    else
         return fail(e, STEPTH_ERR_BAD_ARG, "unknown mode %u", p.mode);
-    }
+    const bool max_published = c.max_published;
 
     if (p.flags & STEPTH_FLAG_GAUSSIAN_TAIL) { // src/depth_image.rs:133-134
         if (raw_only || row0 != 0 || row1 != H)
@@ -1485,7 +1559,7 @@ static int ring_queries_batch(stepth_engine *e, uint32_t nf, const stepth_image 
     if (use_list)
         TRY(launch_list(e, ra, nf, fused_paint ? &pa : nullptr));
     else
-        TRY(launch_ring(e, ra, 1, nf));
+        TRY(launch_legacy_search(e, ra, 1, nf));
 
     if (fused_paint) {
         hipLaunchKernelGGL(paint_big_kernel, dim3(64, nf), dim3(256), 0, e->stream, pa,
@@ -1679,7 +1753,7 @@ int stepth_depth_from_additional_batch(stepth_engine *e, uint32_t n_frames,
         if (use_tile)
             TRY(launch_tile(e, ra, nf));
         else if (ra.n_slots)
-            TRY(launch_ring(e, ra, 0, nf));
+            TRY(launch_legacy_search(e, ra, 0, nf));
 
         PaintArgs pa{};
         pa.raw = ra.raw;
@@ -2069,7 +2143,7 @@ int stepth_distance_dot_array_batch(stepth_engine *e, const stepth_image *array,
     if (use_list)
         TRY(launch_list(e, ra, 1));
     else
-        TRY(launch_ring(e, ra, 1));
+        TRY(launch_legacy_search(e, ra, 1));
     HIP_TRY(e, hipMemcpyAsync(dist, ra.raw32, n * 4, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipMemcpyAsync(pos_xy, ra.pos, n * 8, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipMemcpyAsync(found, ra.found, n, hipMemcpyDeviceToHost, e->stream));
