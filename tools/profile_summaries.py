@@ -26,11 +26,11 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNEL_SOURCES = ["tile_kernels.h", "tile_lane.h", "cell_pack.h", "ring_kernels.h", "engine.hip"]
-DOMINANT = "ring_tile_kernel<false>"
+DOMINANT = "ring_tile_kernel<false, false>"
 STEPS, WARMUP = 6, 2
 CMD = f"python bench.py --steps {STEPS} --warmup {WARMUP} --no-cpu-baseline --no-extra-legs"
 LEGS = {  # directory under the profile root -> (what ran, the kernel the leg is about)
-    "asset": ("python tools/leg_time.py asset 128 hf  (8 x 1080p natural frames, heavy-first order)", "ring_tile_kernel<false>"),
+    "asset": ("python tools/leg_time.py asset 128 hf  (8 x 1080p natural frames, STEPTH_FLAG_HEAVY_FIRST: order + pooled probes)", "ring_tile_kernel<false, true>"),
     "adaptive": ("python tools/leg_adaptive.py bench  (adaptive flow, 8 x 1080p synthetic)", "ring_list_kernel<false>"),
     "adaptive_asset": ("python tools/leg_adaptive.py asset  (adaptive flow, 8 x 1080p natural)", "ring_list_kernel<false>"),
     "sad": ("python tools/leg_sad.py  (windowed SAD 5x5, d_max 128, 4 x 3840x2160)", "sad_search_kernel<5, 16, 16>"),
@@ -69,7 +69,7 @@ def headline_groups(agg):
     """per kernel the launches of its largest grid; STATS variants dropped"""
     best = {}
     for (k, grid) in agg:
-        if "<true>" in k:
+        if "<true" in k:
             continue
         if k not in best or grid > best[k]:
             best[k] = grid
