@@ -20,7 +20,9 @@ roofline: HBM-bound by contract (scan/compare, no MFMA).  achieved = algorithmic
   SURVEY.md 8d) / that kernel's mean launch time, measured live with HIP events on the
   engine's stream; peak = 8 TB/s.  The ring search is data dependent, so the number of items
   examined per pixel is printed next to it.  `traffic` = HBM bytes per launch from the
-  committed rocprofv3 PMC passes (profiles/r2_hbm_traffic.json), valid for the profiled shape.
+  committed rocprofv3 PMC passes (profiles/r3_hbm_traffic.json: means over the headline step's
+  launches only), valid for the profiled shape; they count requests leaving the L2 -- the headline
+  cycles one frame set that fits the 256 MB Infinity Cache, so part of it never reaches HBM.
 cpu_baseline: the C restatement of the reference algorithm (oracle/, "port" -- NOT the Rust
   binary) on one frame of the same workload, all host cores with dynamic scheduling, plus the
   reference's own static 8-chunk partition (src/depth_image.rs:111-112) as `ref8_value`.
@@ -55,7 +57,7 @@ import torch.distributed as dist
 
 HBM_PEAK_GBS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
 ALGO_BYTES_PER_PIXEL = 7.0
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r2_hbm_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r3_hbm_traffic.json")
 DOMINANT_KERNEL = "ring_tile_kernel"  # tests/test_bench_contract.py checks the profile names it
 
 
@@ -538,8 +540,8 @@ def main():
                              "valu_busy_frac": round(min(sq["SQ_ACTIVE_INST_VALU"] / simd_quad_cycles, 1.0), 3),
                              "waves_resident_per_simd": round(sq.get("SQ_WAVE_CYCLES", 0) / simd_quad_cycles, 2),
                              "cycles_per_wave64_int_valu_inst": 3.9,
-                             "source": "profiles/r2_hbm_traffic.json (rocprofv3 --pmc SQ_*), "
-                                       "profiles/r2_issue_microbench.txt"}
+                             "source": "profiles/r3_hbm_traffic.json (rocprofv3 --pmc SQ_*), "
+                                       "profiles/r3_issue_microbench.txt"}
         n_slots = max(1, args.streams)
         out = {
             "metric": ("Mpixels/sec depth output, 1080p stereo d_max=128" if args.mode == "ring"

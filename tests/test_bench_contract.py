@@ -1,6 +1,6 @@
 """CPU-side guards of what bench.py reports (no GPU, no bench run):
 
-* `roofline.traffic` is quoted from profiles/r2_hbm_traffic.json; that file names the kernels it
+* `roofline.traffic` is quoted from profiles/r3_hbm_traffic.json; that file names the kernels it
   was measured on and the hash of their sources.  If the kernels of the headline step are
   renamed / replaced, or the dominant kernel changes, this fails -- the profile cannot go stale
   silently; and bench.py itself drops `traffic` (null) as soon as the source hash differs.
@@ -44,7 +44,7 @@ def _launched_in(function_names):
 def test_traffic_profile_names_the_kernels_the_headline_step_launches():
     _spec, bench_src = _bench()
     dominant = re.search(r'DOMINANT_KERNEL = "([a-z0-9_]+)"', bench_src).group(1)
-    prof = json.load(open(os.path.join(ROOT, "profiles", "r2_hbm_traffic.json")))
+    prof = json.load(open(os.path.join(ROOT, "profiles", "r3_hbm_traffic.json")))
     assert dominant in prof["dominant_kernel"]
     profiled = {re.sub(r"^stepth::", "", re.sub(r"<.*", "", k)) for k in prof["headline_step_kernels"]}
     # the one-group-per-pixel batch: pack (+ superblock fold), the dense search, paint; the
@@ -54,6 +54,16 @@ def test_traffic_profile_names_the_kernels_the_headline_step_launches():
     launched -= {"tile_cost_kernel", "tile_scan_kernel", "tile_scatter_kernel"}
     assert launched == {"tile_pack_kernel", "tile_super_kernel", "ring_tile_kernel"}, launched
     assert launched <= profiled, f"profile lacks {launched - profiled}: re-run tools/run_profiles.sh"
+    # per-launch means are over the headline step's launches only: every kernel of the step shows
+    # exactly steps + warmup calls (the statistics leg's one-frame launches are left out), and the
+    # step's traffic is the sum of exactly those kernels
+    assert {v["calls"] for v in prof["kernels"].values()} == {prof["steps_plus_warmup"]}, prof["kernels"]
+    assert not any("<true" in k for k in prof["kernels"]), "STATS variants do not belong to the headline step"
+    assert prof["headline_step_traffic_bytes_corrected"] == sum(v["corrected_bytes_per_launch"] for v in prof["kernels"].values())
+    assert abs(prof["headline_step_traffic_over_algorithmic"] -
+               prof["headline_step_traffic_bytes_corrected"] / prof["algorithmic_bytes_per_launch"]) < 0.01
+    for leg in ("asset", "adaptive", "sad"):  # the PMC passes of the other dominant kernels exist
+        assert leg in prof["other_legs_dominant_kernel"], leg
     assert profiled - launched <= {"paint_1x1_vec4_kernel", "paint_tiles_kernel", "normalise_rows_kernel"}, profiled
     for k in profiled:  # every profiled kernel still exists in the sources
         assert any(re.search(r"\b" + k + r"\b", open(os.path.join(CSRC, f)).read())
@@ -69,7 +79,7 @@ def test_bench_quotes_traffic_only_for_current_kernel_sources():
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import profile_summaries
-    prof = json.load(open(os.path.join(ROOT, "profiles", "r2_hbm_traffic.json")))
+    prof = json.load(open(os.path.join(ROOT, "profiles", "r3_hbm_traffic.json")))
     assert prof["kernel_sources"] == profile_summaries.KERNEL_SOURCES
     assert re.fullmatch(r"[0-9a-f]{16}", prof["kernel_source_sha16"])
 
