@@ -674,9 +674,9 @@ def main():
                 out["adaptive_flow"] = {
                     "value": round(px_step / adt / 1e6, 1), "unit": "Mpixels/s",
                     "ms_per_call": round(adt * 1e3, 4),
-                    "workload": f"{n_frames} frames: stepth_adaptive_groups_batch -> ring first-hit per "
-                                "group -> normalise -> paint, groups never leave the device "
-                                "(grouping rule: this engine's own, parity with disage unpinned)"}
+                    "workload": f"{n_frames} frames: stepth_adaptive_depth_batch = adaptive groups -> ring first-hit per "
+                                "group (the search paints its rectangles itself) -> normalise in place; groups never "
+                                "leave the device (grouping rule: this engine's own, parity with disage unpinned)"}
                 if O is not None:
                     d0, _ = eng.adaptive_depth_batch(mains_t[:1], adds_t[:1], prec, max_steps=args.d_max)
                     g = O.adaptive_groups(frames_np[0][0], prec)
