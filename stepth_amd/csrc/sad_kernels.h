@@ -82,18 +82,22 @@ constexpr int kSadPadD = 16; // extra left apron of the R plane: the last chunk 
 
 // ROWS = output rows per wave: 16 costs (16+WIN-1)/16 input rows per output row, 8 costs more
 // but gives small frames twice the waves
+// One wave per workgroup (round 3): a strip whose pixels are all decided by the threshold stops
+// early, and with four waves per workgroup the early ones' LDS stayed allocated until the last
+// was done -- five half-empty workgroups held a CU's LDS and nothing new could start (2.0 of 4
+// possible waves per SIMD resident, VALU 58 % busy; profiles/r3_sq_counters.txt).
 template <int WIN, int DC, int ROWS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void sad_search_kernel(SadArgs a)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void sad_search_kernel(SadArgs a)
 {
     constexpr int RAD = WIN / 2;
     constexpr int kSadRows = ROWS;
-    __shared__ uint32_t s_best[4][kSadRows][64]; // running min cost
-    __shared__ uint32_t s_pick[4][kSadRows][64]; // bit 31: decided (under threshold); low: d
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int x = ((int)blockIdx.x * 4 + wv) * 64 + lane;          // output column
+    __shared__ uint32_t s_best[1][kSadRows][64]; // running min cost
+    __shared__ uint32_t s_pick[1][kSadRows][64]; // bit 31: decided (under threshold); low: d
+    const int lane = threadIdx.x & 63, wv = 0;
+    const int x = (int)blockIdx.x * 64 + lane;                     // output column
     const int ys = (int)a.row0 + (int)blockIdx.y * kSadRows;       // first output row
     const int nrows = min(kSadRows, (int)a.row1 - ys);
-    if (((int)blockIdx.x * 4 + wv) * 64 >= (int)a.w) // whole wave outside (uniform)
+    if ((int)blockIdx.x * 64 >= (int)a.w) // whole wave outside (uniform)
         return;
 #pragma unroll
     for (int r = 0; r < kSadRows; ++r) {
@@ -319,16 +323,16 @@ inline int launch_sad_pack(const SadArgs &a, hipStream_t stream)
 inline int launch_sad(const SadArgs &a, hipStream_t stream)
 {
     if (sad_has_fast_path(a.win)) {
-        const uint32_t cols = (a.w + 255) / 256, rows = a.row1 - a.row0;
+        const uint32_t cols = (a.w + 63) / 64, rows = a.row1 - a.row0; // one wave (64 columns) per workgroup
         // enough waves to fill 256 CUs x 12 wave slots with 16-row strips?
-        const bool tall = (size_t)cols * 4 * ((rows + 15) / 16) * a.n_frames >= 6144;
+        const bool tall = (size_t)cols * ((rows + 15) / 16) * a.n_frames >= 6144;
         const dim3 grid(cols, tall ? (rows + 15) / 16 : (rows + 7) / 8, a.n_frames);
 #define STEPTH_SAD_LAUNCH(W, D)                                                               \
     do {                                                                                      \
         if (tall)                                                                             \
-            hipLaunchKernelGGL((sad_search_kernel<W, D, 16>), grid, dim3(256), 0, stream, a); \
+            hipLaunchKernelGGL((sad_search_kernel<W, D, 16>), grid, dim3(64), 0, stream, a);  \
         else                                                                                  \
-            hipLaunchKernelGGL((sad_search_kernel<W, D, 8>), grid, dim3(256), 0, stream, a);  \
+            hipLaunchKernelGGL((sad_search_kernel<W, D, 8>), grid, dim3(64), 0, stream, a);   \
     } while (0)
         switch (a.win) {
         case 3: STEPTH_SAD_LAUNCH(3, 16); break;
