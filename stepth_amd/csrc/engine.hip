@@ -505,7 +505,7 @@ int launch_list(stepth_engine *e, const RingArgs &ra, uint32_t n_frames, const P
     // few queries (one frame's group list, a thin strip): fewer queries per wave, more waves
     const uint64_t total = (uint64_t)ra.n * n_frames;
     la.lanes = total >= (1u << 18) ? 64u : total >= (1u << 16) ? 32u : 16u;
-    const dim3 grid((ra.n + 4u * la.lanes - 1u) / (4u * la.lanes), n_frames), block(256);
+    const dim3 grid((ra.n + la.lanes - 1u) / la.lanes, n_frames), block(64); // one wave per workgroup
     {
         KernelTimer t(e);
         if (e->stats_enabled)

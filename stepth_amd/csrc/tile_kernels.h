@@ -808,19 +808,22 @@ constexpr uint64_t kNearLe[4] = {0x0000000008000000ull, 0x0000001C1C1C0000ull,
 constexpr uint32_t kListPoolCap = 128, kListFlushMin = 16;
 
 template <bool STATS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void ring_list_kernel(ListArgs a)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void ring_list_kernel(ListArgs a)
 {
-    __shared__ uint2 s_box[4][64];            // per wave: the queries as the tasks see them: box {lo, hi},
-    __shared__ uint2 s_qxy[4][64];            // centre,
-    __shared__ uint32_t s_best[4][64];        // smallest key so far (merged by minimum),
-    __shared__ uint32_t s_lim[4][64];         // its limit;
-    __shared__ uint32_t s_task[4][kListPoolCap]; // the pool: query lane | block x << 6 | block y << 19
+    // One wave per workgroup: the waves share nothing, and their run times differ by an order of
+    // magnitude -- in a workgroup of four the slots of the early ones stayed taken until the last
+    // was done.
+    __shared__ uint2 s_box[1][64];            // the queries as the tasks see them: box {lo, hi},
+    __shared__ uint2 s_qxy[1][64];            // centre,
+    __shared__ uint32_t s_best[1][64];        // smallest key so far (merged by minimum),
+    __shared__ uint32_t s_lim[1][64];         // its limit;
+    __shared__ uint32_t s_task[1][kListPoolCap]; // the pool: query lane | block x << 6 | block y << 19
     const uint32_t lane = threadIdx.x & 63u, f = blockIdx.y;
-    const uint32_t wv = rfl(threadIdx.x >> 6);
+    constexpr uint32_t wv = 0;
     // a wave takes `lanes` (16, 32 or 64) consecutive queries: a small launch is bound by the
     // latency of its slowest wave, not by issue slots, and a wave of fewer queries has fewer
     // windows to sit through
-    const uint32_t i = (blockIdx.x * 4u + (threadIdx.x >> 6)) * a.lanes + lane;
+    const uint32_t i = blockIdx.x * a.lanes + lane;
     const bool valid = lane < a.lanes && i < a.nq[f];
     const uint32_t tf = f * a.t_stride;
     const uint2 *BBf = a.BBp + (size_t)f * a.bb_stride;
