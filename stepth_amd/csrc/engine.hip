@@ -397,7 +397,7 @@ int launch_tile(stepth_engine *e, const RingArgs &ra, uint32_t n_frames)
     ta.cby_n = ((ra.row1 >> 1) >> 3) - ta.cby0 + 1u;
     ta.n_rows = ta.cby_n * n_frames;
     const uint64_t n_wg = (uint64_t)((ta.n_rows + 7u) / 8u) * 8u * ta.cbx_n; // rows dealt to 8 XCDs
-    if (n_wg > 0x7FFFFFF0ull)
+    if (n_wg > 0x1FFFFFF0ull)
         return fail(e, STEPTH_ERR_BAD_ARG, "too many centre blocks in one launch");
     // a search never leaves the array: more steps than its longer side change nothing
     ta.max_steps = std::min(ra.max_steps, std::max(ra.wa, ra.ha));
@@ -413,7 +413,7 @@ int launch_tile(stepth_engine *e, const RingArgs &ra, uint32_t n_frames)
     ta.raw_stride = (uint32_t)(((size_t)ra.n + 3u) & ~(size_t)3u);
     ta.max_word = ra.max_word;
     ta.stats = e->stats_enabled ? e->stats : nullptr;
-    const dim3 grid((uint32_t)n_wg), block(256);
+    const dim3 grid((uint32_t)n_wg * 4u), block(64); // one wave per workgroup, four per tile
     // heavy-first launch order (STEPTH_FLAG_HEAVY_FIRST): worth its three small launches only
     // when the search kernel runs many rounds of workgroups
     if (ra.heavy_first && n_wg >= 8192u && !e->stats_enabled) { // (a 1080p frame has 8228)

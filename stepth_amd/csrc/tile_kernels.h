@@ -130,25 +130,30 @@ constexpr uint32_t kPoolCap = 128, kPoolFlushMin = 16;
 // "Residency": 800 / (sgprs + 16)); the kernel wants 106, the spills to vector lanes cost less
 // than the eighth wave per SIMD brings (1.28 -> 1.22 ms; 96: 1.23, 64: 1.24)
 template <bool STATS, bool POOL = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void ring_tile_kernel(TileArgs a)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void ring_tile_kernel(TileArgs a)
 {
     // POOL: per wave the queries as the probe tasks see them, and the task pool
-    __shared__ uint2 s_box[POOL ? 4 : 1][POOL ? 64 : 1];           // colour box {lo, hi}
-    __shared__ uint32_t s_best[POOL ? 4 : 1][POOL ? 64 : 1];       // smallest key so far (merged by minimum)
-    __shared__ uint32_t s_lim[POOL ? 4 : 1][POOL ? 64 : 1];        // its limit
-    __shared__ uint32_t s_task[POOL ? 4 : 1][POOL ? kPoolCap : 1]; // query lane | block x << 6 | block y << 19
+    __shared__ uint2 s_box[1][POOL ? 64 : 1];           // colour box {lo, hi}
+    __shared__ uint32_t s_best[1][POOL ? 64 : 1];       // smallest key so far (merged by minimum)
+    __shared__ uint32_t s_lim[1][POOL ? 64 : 1];        // its limit
+    __shared__ uint32_t s_task[1][POOL ? kPoolCap : 1]; // query lane | block x << 6 | block y << 19
     [[maybe_unused]] unsigned long long pc_tests = 0, pc_survey = 0, pc_probe = 0;
     [[maybe_unused]] ProbeCounters pcnt{};
     [[maybe_unused]] const unsigned long long pc_t0 = STEPTH_TICK();
+    // One wave per workgroup (the four waves of a tile share nothing but its position): block
+    // x = xcd + 8 * (wave + 4 * tile-within-XCD), so a tile's waves stay on one XCD and follow each
+    // other in the dispatch order.
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wv = rfl(threadIdx.x >> 6);
+    const uint32_t wv = (blockIdx.x >> 3) & 3u;
+    constexpr uint32_t lw = 0; // the wave's row of the LDS arrays
     // Workgroup ids go round-robin over the 8 XCDs.  Rows of centre blocks (the frames of a batch
     // stacked) are dealt to the XCDs in turn: every XCD gets an eighth of every frame and of
     // every part of it -- frames and image regions differ a lot in work, and an XCD that owned
     // one frame (or one band of a single frame) finished well before or after the others
     // (1.16 -> 1.02 ms on the bench frames).  The workgroups an XCD runs at one time are still
     // neighbours in a row and read the same cells through its L2.
-    const uint32_t bid = a.order ? a.order[blockIdx.x] : blockIdx.x;
+    const uint32_t tb = (blockIdx.x & 7u) + 8u * (blockIdx.x >> 5); // the tile's place in the launch order
+    const uint32_t bid = a.order ? a.order[tb] : tb;
     const uint32_t xcd = bid & 7u, xi = bid >> 3;
     const uint32_t g = xcd + 8u * (xi / a.cbx_n); // row of centre blocks, all frames stacked
     if (g >= a.n_rows)
@@ -208,19 +213,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void ring
     // the kernel's end).
     [[maybe_unused]] auto flush = [&]() __attribute__((always_inline)) {
         if constexpr (POOL) {
-            s_best[wv][lane] = q.best; // what the lane found out about its own query meanwhile
-            s_lim[wv][lane] = q.limit;
+            s_best[lw][lane] = q.best; // what the lane found out about its own query meanwhile
+            s_lim[lw][lane] = q.limit;
             for (uint32_t base = 0; base < n_pool; base += 64u) {
                 const uint32_t ti = base + lane;
                 if (ti < n_pool) {
-                    const uint32_t t = s_task[wv][ti], src = t & 63u;
+                    const uint32_t t = s_task[lw][ti], src = t & 63u;
                     const int bx = (int)((t >> 6) & 0x1FFFu), by = (int)(t >> 19);
                     LaneQ tq;
-                    const uint2 box = s_box[wv][src];
+                    const uint2 box = s_box[lw][src];
                     tq.lo = box.x;
                     tq.hi = box.y;
-                    tq.best = s_best[wv][src];
-                    tq.limit = s_lim[wv][src];
+                    tq.best = s_best[lw][src];
+                    tq.limit = s_lim[lw][src];
                     tq.qx = CBX * 8 + (int)((wv & 1u) * 4u + ((src >> 2) & 3u));
                     tq.qy = CBY * 8 + (int)((wv >> 1) * 4u + (src >> 4));
                     const int x0 = bx * 8 - tq.qx, y0 = by * 8 - tq.qy;
@@ -231,8 +236,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void ring
                         const uint32_t nl = probe_block(tq, x0, y0, pb, a.T + boff, a.TT + boff,
                                                         reinterpret_cast<const uint32_t *>(a.LB) + (boff >> 1), &pcnt);
                         if (tq.best < best_before) {
-                            atomicMin(&s_best[wv][src], tq.best);
-                            atomicMin(&s_lim[wv][src], tq.limit);
+                            atomicMin(&s_best[lw][src], tq.best);
+                            atomicMin(&s_lim[lw][src], tq.limit);
                         }
                         if constexpr (STATS) {
                             ++n_probed;
@@ -245,18 +250,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void ring
             n_pool = 0u;
             uint32_t l2 = lane;
             asm("" : "+v"(l2)); // (opaque: keeps the compiler from carrying the values across instead)
-            const uint2 box = s_box[wv][l2];
+            const uint2 box = s_box[lw][l2];
             q.lo = box.x;
             q.hi = box.y;
-            q.best = s_best[wv][l2];
-            q.limit = s_lim[wv][l2];
+            q.best = s_best[lw][l2];
+            q.limit = s_lim[lw][l2];
             q.qx = CBX * 8 + (int)((wv & 1u) * 4u + ((l2 >> 2) & 3u));
             q.qy = CBY * 8 + (int)((wv >> 1) * 4u + (l2 >> 4));
         }
     };
     if (__builtin_amdgcn_ballot_w64(q.limit != 0u)) {
         if constexpr (POOL)
-            s_box[wv][lane] = make_uint2(q.lo, q.hi);
+            s_box[lw][lane] = make_uint2(q.lo, q.hi);
         // superblock window of the wave (far phase): every lane's window of radius
         // max_steps-1 lies inside it
         const int R = (int)a.max_steps - 1;
@@ -451,7 +456,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void ring
                         }
                         const unsigned long long okm = __builtin_amdgcn_ballot_w64(ok);
                         if (ok)
-                            s_task[wv][n_pool + __builtin_amdgcn_mbcnt_hi((uint32_t)(okm >> 32),
+                            s_task[lw][n_pool + __builtin_amdgcn_mbcnt_hi((uint32_t)(okm >> 32),
                                                                            __builtin_amdgcn_mbcnt_lo((uint32_t)okm, 0u))] = task;
                         n_pool += (uint32_t)__builtin_popcountll(okm);
                     }
