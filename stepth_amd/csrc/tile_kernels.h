@@ -596,32 +596,33 @@ struct TileOrderBufs {
 __global__ __launch_bounds__(1024) void tile_cost_kernel(TileArgs a, TileOrderBufs o)
 {
     __shared__ uint2 s_win[64][49]; // per tile of the group: the 7x7 block bounds around its centre block
+    __shared__ int4 s_tile[64];     // per tile: frame, CBX, CBY, 1 = there is one (the divisions once per tile)
     __shared__ uint8_t s_cls[64];
     const uint32_t s = threadIdx.x & 15u, tl = threadIdx.x >> 4;
-    // tile t = the workgroup id of ring_tile_kernel
-    auto tile_of = [&](uint32_t t, uint32_t &f, int &CBX, int &CBY) -> bool {
-        const uint32_t xcd = t & 7u, xi = t >> 3, g = xcd + 8u * (xi / a.cbx_n);
-        if (t >= o.n_wg || g >= a.n_rows)
-            return false;
-        f = g / a.cby_n;
-        CBY = (int)(a.cby0 + g % a.cby_n);
-        CBX = (int)(xi % a.cbx_n);
-        return true;
-    };
+    if (threadIdx.x < 64u) {
+        // tile t = the tile's place in ring_tile_kernel's launch order
+        const uint32_t t = blockIdx.x * 64u + threadIdx.x, xcd = t & 7u, xi = t >> 3, g = xcd + 8u * (xi / a.cbx_n);
+        int4 v = make_int4(0, 0, 0, 0);
+        if (t < o.n_wg && g < a.n_rows)
+            v = make_int4((int)(g / a.cby_n), (int)(xi % a.cbx_n), (int)(a.cby0 + g % a.cby_n), 1);
+        s_tile[threadIdx.x] = v;
+    }
+    __syncthreads();
     // ---- the groups' windows -> LDS (the 16 samples of a tile test the same 49 blocks) ----
     for (uint32_t i = threadIdx.x; i < 64u * 49u; i += 1024u) {
         const uint32_t wt = i / 49u, e = i - wt * 49u, dy = e / 7u, dx = e - dy * 7u;
-        uint32_t f;
-        int CBX, CBY;
+        const int4 ti = s_tile[wt];
         uint2 b = make_uint2(0u, kNoCell);
-        if (tile_of(blockIdx.x * 64u + wt, f, CBX, CBY))
-            b = a.BBp[(size_t)f * a.bb_stride + (size_t)(CBY - 3 + (int)dy + kPadB) * a.bwp + (size_t)(CBX - 3 + (int)dx + kPadB)];
+        if (ti.w)
+            b = a.BBp[(size_t)ti.x * a.bb_stride + (size_t)(ti.z - 3 + (int)dy + kPadB) * a.bwp + (size_t)(ti.y - 3 + (int)dx + kPadB)];
         s_win[wt][e] = b;
     }
     __syncthreads();
-    uint32_t w = 0, f;
-    int CBX, CBY;
-    if (tile_of(blockIdx.x * 64u + tl, f, CBX, CBY)) {
+    uint32_t w = 0;
+    const int4 ti = s_tile[tl];
+    if (ti.w) {
+        const uint32_t f = (uint32_t)ti.x;
+        const int CBX = ti.y, CBY = ti.z;
         const uint32_t cx = (uint32_t)CBX * 8u + 2u * (s & 3u), cy = (uint32_t)CBY * 8u + 2u * (s >> 2);
         const uint32_t x = 2u * cx, y = 2u * cy;
         if (x < a.w && y >= a.row0 && y < a.row1 && a.rp.owns(y) && cx < a.wa && cy < a.ha && a.max_steps > 1u) {
@@ -637,7 +638,9 @@ __global__ __launch_bounds__(1024) void tile_cost_kernel(TileArgs a, TileOrderBu
                 w = 4u; // a short reach: how far matters little next to how many (measured)
             } else if (!near) {
                 const uint2 *SBf = a.SBp + (size_t)f * a.sb_stride;
-                const int R = (int)a.max_steps - 1, qx = (int)cx, qy = (int)cy;
+                // (superblocks up to 159 rings away: whatever meets nothing nearer counts as the
+                // full reach -- a 6x6 survey instead of up to 9x9)
+                const int R = min((int)a.max_steps - 1, 159), qx = (int)cx, qy = (int)cy;
                 const int sx0 = max(qx - R, 0) >> 6, sy0 = max(qy - R, 0) >> 6;
                 const int sx1 = min(qx + R, (int)a.wa - 1) >> 6, sy1 = min(qy + R, (int)a.ha - 1) >> 6;
                 uint32_t dmin = 255u;
@@ -645,7 +648,7 @@ __global__ __launch_bounds__(1024) void tile_cost_kernel(TileArgs a, TileOrderBu
                     for (int sx = sx0; sx <= sx1; ++sx) {
                         const uint2 sb = SBf[(size_t)sy * a.sbwp + sx];
                         const uint32_t dS = (uint32_t)square_dmin((sx << 6) - qx, (sy << 6) - qy, 64);
-                        if (dS < a.max_steps && box_meets(sb.x, sb.y, lo, hi))
+                        if (dS <= (uint32_t)R && box_meets(sb.x, sb.y, lo, hi))
                             dmin = min(dmin, dS);
                     }
                 w = min(max(dmin, 25u), 255u) >> 4; // 1..15
@@ -697,7 +700,8 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v)
 // (o.off[n_groups * 16 ..]; word 16 = 1: identity order, class 0 is not the majority).
 __global__ __launch_bounds__(1024) void tile_scan_kernel(TileOrderBufs o)
 {
-    __shared__ uint4 s_cnt[1024]; // 16 class sizes (bytes) per group
+    __shared__ uint4 s_cnt[1024];        // 16 class sizes (bytes) per group
+    __shared__ uint32_t s_off[1024][17]; // the turn's offsets (17: no bank conflicts between the waves' columns)
     __shared__ uint32_t s_total[16];
     const uint32_t lane = threadIdx.x & 63u, c = threadIdx.x >> 6;
     uint32_t run = 0;
@@ -709,9 +713,16 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(TileOrderBufs o)
             const uint32_t g = j * 64u + lane;
             const uint32_t n = reinterpret_cast<const uint8_t *>(&s_cnt[g])[c];
             const uint32_t inc = wave_scan_incl(n);
-            if (g0 + g < o.n_groups)
-                o.off[(size_t)(g0 + g) * 16u + c] = run + inc - n;
+            s_off[g][c] = run + inc - n;
             run += bcast(inc, 63);
+        }
+        __syncthreads();
+        if (gl < o.n_groups) { // the group's 16 offsets in one 64-byte piece
+            uint4 *dst = reinterpret_cast<uint4 *>(o.off + (size_t)gl * 16u);
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4)
+                dst[q4] = make_uint4(s_off[threadIdx.x][4 * q4], s_off[threadIdx.x][4 * q4 + 1], s_off[threadIdx.x][4 * q4 + 2],
+                                     s_off[threadIdx.x][4 * q4 + 3]);
         }
         __syncthreads();
     }
