@@ -750,6 +750,85 @@ __global__ __launch_bounds__(256) void tile_scatter_kernel(TileOrderBufs o)
     o.order[base[16] ? t : base[c] + o.off[(size_t)(t >> 6) * 16u + c] + o.rank[t]] = t;
 }
 
+// Heavy-first order for ring_list_kernel: the same estimate per WAVE of 64 sorted queries (the
+// waves are what the kernel's tail is made of: 2.2 of 4 wave slots filled on average).  A query
+// whose box meets none of the 7x7 block bounds around its centre block weighs 4 (reach <= 160)
+// or the distance of the nearest meeting superblock within 159 rings / 16; the wave's key is the
+// sum, the classes, scan and scatter are those of the dense search (groups of 64 waves).
+struct ListCostArgs {
+    const uint2 *BBp, *SBp;
+    uint32_t wa, ha, bwp, sbwp, bb_stride, sb_stride;
+    const Query *queries;
+    uint32_t q_stride, wpf, max_steps;
+    uint32_t nq[kMaxBatch];
+};
+
+__global__ __launch_bounds__(256) void list_cost_kernel(ListCostArgs a, TileOrderBufs o)
+{
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t wid = blockIdx.x * 4u + wv; // one workgroup = 4 waves of the search
+    uint32_t w = 0;
+    if (wid < o.n_wg) {
+        const uint32_t f = wid / a.wpf, i = (wid - f * a.wpf) * 64u + lane;
+        if (i < a.nq[f]) {
+            const Query q = a.queries[(size_t)f * a.q_stride + i];
+            if (q.cx < a.wa && q.cy < a.ha && a.max_steps > 1u) {
+                const int cbx = (int)(q.cx >> 3), cby = (int)(q.cy >> 3);
+                const uint2 *BBf = a.BBp + (size_t)f * a.bb_stride;
+                bool near = false;
+                for (int dy = -3; dy <= 3; ++dy) {
+                    const uint2 *row = BBf + (size_t)(cby + dy + kPadB) * a.bwp + (size_t)(cbx - 3 + kPadB);
+#pragma unroll
+                    for (int dx = 0; dx < 7; ++dx)
+                        near |= box_meets(row[dx].x, row[dx].y, q.lo, q.hi);
+                }
+                if (!near && a.max_steps <= 160u) {
+                    w = 4u;
+                } else if (!near) {
+                    const uint2 *SBf = a.SBp + (size_t)f * a.sb_stride;
+                    const int R = min((int)a.max_steps - 1, 159), qx = (int)q.cx, qy = (int)q.cy;
+                    const int sx0 = max(qx - R, 0) >> 6, sy0 = max(qy - R, 0) >> 6;
+                    const int sx1 = min(qx + R, (int)a.wa - 1) >> 6, sy1 = min(qy + R, (int)a.ha - 1) >> 6;
+                    uint32_t dmin = 255u;
+                    for (int sy = sy0; sy <= sy1; ++sy)
+                        for (int sx = sx0; sx <= sx1; ++sx) {
+                            const uint2 sb = SBf[(size_t)sy * a.sbwp + sx];
+                            const uint32_t dS = (uint32_t)square_dmin((sx << 6) - qx, (sy << 6) - qy, 64);
+                            if (dS <= (uint32_t)R && box_meets(sb.x, sb.y, q.lo, q.hi))
+                                dmin = min(dmin, dS);
+                        }
+                    w = min(max(dmin, 25u), 255u) >> 4;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int sh = 1; sh < 64; sh <<= 1)
+        w += (uint32_t)__shfl_xor((int)w, sh, 64);
+    if (wid < o.n_wg && lane == 0)
+        o.cls[wid] = (uint8_t)min(isqrt_floor(w >> 2), 15u); // (64 queries per wave against 16 samples per tile)
+}
+
+// ranks and class sizes per group of 64 waves, from the classes list_cost_kernel wrote
+__global__ __launch_bounds__(64) void list_rank_kernel(TileOrderBufs o)
+{
+    const uint32_t wid = blockIdx.x * 64u + threadIdx.x;
+    const uint32_t c = wid < o.n_wg ? o.cls[wid] : 16u;
+    uint32_t rank = 0, mine = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 16u; ++k) {
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(c == k);
+        if (c == k)
+            rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        if (threadIdx.x == k)
+            mine = (uint32_t)__builtin_popcountll(m);
+    }
+    if (wid < o.n_wg)
+        o.rank[wid] = (uint8_t)rank;
+    if (threadIdx.x < 16u)
+        o.cnt[(size_t)blockIdx.x * 16u + threadIdx.x] = (uint8_t)mine;
+}
+
 // ---------------------------------------------------------------------------------------
 // PASS 1 for PREPARED QUERIES (explicit group lists, uniform tiles larger than one pixel,
 // stepth_distance_dot_array_batch): src/depth_image.rs:112-123 for arbitrary `middle`s.
@@ -790,6 +869,10 @@ struct ListArgs {
     uint32_t paint_w, paint_h, paint_row0, paint_row1;
     uint32_t *big_count, *big_list; // per frame: count, list of `big_cap` slots
     uint32_t big_cap;
+    // waves of all frames in one launch order: wave w of frame f = wid f * wpf + w; optional
+    // heavy-first order (list_cost_kernel below): workgroup blockIdx.x takes wave order[blockIdx.x]
+    uint32_t wpf;
+    const uint32_t *order;
 };
 
 // eight bound tests of one row of blocks held in vector registers, highest column first
@@ -834,12 +917,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     __shared__ uint32_t s_best[1][64];        // smallest key so far (merged by minimum),
     __shared__ uint32_t s_lim[1][64];         // its limit;
     __shared__ uint32_t s_task[1][kListPoolCap]; // the pool: query lane | block x << 6 | block y << 19
-    const uint32_t lane = threadIdx.x & 63u, f = blockIdx.y;
+    const uint32_t lane = threadIdx.x & 63u;
     constexpr uint32_t wv = 0;
+    const uint32_t wid = a.order ? a.order[blockIdx.x] : blockIdx.x;
+    const uint32_t f = wid / a.wpf;
     // a wave takes `lanes` (16, 32 or 64) consecutive queries: a small launch is bound by the
     // latency of its slowest wave, not by issue slots, and a wave of fewer queries has fewer
     // windows to sit through
-    const uint32_t i = blockIdx.x * a.lanes + lane;
+    const uint32_t i = (wid - f * a.wpf) * a.lanes + lane;
     const bool valid = lane < a.lanes && i < a.nq[f];
     const uint32_t tf = f * a.t_stride;
     const uint2 *BBf = a.BBp + (size_t)f * a.bb_stride;

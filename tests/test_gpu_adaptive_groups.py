@@ -178,3 +178,36 @@ def test_batched_uniform_tiles_match_oracle(engine, oracle):
         raw = oracle.depth_from_additional(l, r, prec, 64, (5, 5))["raw"]
         got = outs[f].cpu().numpy()
         assert np.array_equal(got[20:60], raw[20:60]) and (got[:20] == 7).all() and (got[60:] == 7).all(), f
+
+
+@pytest.mark.gpu
+def test_long_reach_list_order_changes_nothing(engine, oracle, asset):
+    """reach > 160 with >= 8192 waves of queries: ring_list_kernel's waves start heaviest first
+    (list_cost / list_rank / tile_scan / tile_scatter kernels).  Same bytes as the unordered
+    launch (the statistics variant keeps list order), one natural frame against the oracle"""
+    import sys
+    import torch
+    from conftest import ROOT
+    sys.path.insert(0, ROOT)
+    from bench import mirror_tile
+    from stepth_amd import synth
+    W, H = 1920, 1080
+    nat = (mirror_tile(asset["main"][..., :3], W, H), mirror_tile(asset["additional"][..., :3], W, H))
+    frames = [nat if f % 2 else synth.stereo_pair(W, H, 128, seed=0xA0 + f)[:2] for f in range(8)]
+    mains = [torch.from_numpy(np.ascontiguousarray(l)).cuda() for l, _ in frames]
+    adds = [torch.from_numpy(np.ascontiguousarray(r)).cuda() for _, r in frames]
+    prec = [36] * 3
+    a, ma = engine.adaptive_depth_batch(mains, adds, prec, max_steps=255)
+    counts = engine.last_group_counts
+    assert sum((c + 63) // 64 for c in counts) >= 8192, counts  # else the order is not taken
+    engine.stats_enable(True)
+    try:
+        b, mb = engine.adaptive_depth_batch(mains, adds, prec, max_steps=255)
+    finally:
+        engine.stats_enable(False)
+    assert list(ma) == list(mb)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    ref = oracle.depth_from_additional(nat[0], nat[1], prec, 255, groups=oracle.adaptive_groups(nat[0], prec, 16, 0))
+    assert ref["status"] == 0 and ma[1] == ref["max"]
+    assert np.array_equal(a[1].cpu().numpy(), ref["depth"])
