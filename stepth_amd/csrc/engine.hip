@@ -286,7 +286,7 @@ bool tile_search_fits(uint32_t max_steps, uint32_t wa, uint32_t ha)
 // RGB8 additional images -> T, TT, padded block bounds, superblock bounds (tile_kernels.h)
 int pack_additional_tiles(stepth_engine *e, uint32_t n_frames, const uint8_t *const *d_adds,
                           size_t stride, uint32_t wa, uint32_t ha, uint32_t &bw, uint32_t &bh,
-                          uint32_t row_lo, uint32_t row_hi)
+                          uint32_t row_lo, uint32_t row_hi, uint32_t col_hi = 0xFFFFFFFFu)
 {
     bw = (wa + 7u) / 8u;
     bh = (ha + 7u) / 8u;
@@ -339,7 +339,12 @@ int pack_additional_tiles(stepth_engine *e, uint32_t n_frames, const uint8_t *co
     pa.n_zero = (uint32_t)(kWordsBytes / 4);
     pa.t_stride = (uint32_t)(nblk * 64);
     pa.bb_stride = (uint32_t)bb_frame;
-    hipLaunchKernelGGL(tile_pack_kernel, dim3((bw + kPackBlocks - 1u) / kPackBlocks, pa.nby, n_frames),
+    // columns the searches can reach (centres lie in the left half of the array, like the rows in
+    // its upper half: middle = ((x + w) / 2, (y + h) / 2), src/depth_image.rs:114-117): blocks
+    // further right keep whatever bounds they had -- empty or an earlier image's -- and are never
+    // probed, exactly like the rows outside [by0, by1) (their nearest cell is beyond every limit)
+    const uint32_t bcols = std::min<uint64_t>(bw, ((uint64_t)col_hi + 7u) / 8u);
+    hipLaunchKernelGGL(tile_pack_kernel, dim3((std::max(bcols, 1u) + kPackBlocks - 1u) / kPackBlocks, pa.nby, n_frames),
                        dim3(256), 0, e->stream, pa);
     TileSuperArgs sa{};
     sa.BBp = pa.BBp;
@@ -416,6 +421,7 @@ int launch_tile(stepth_engine *e, const RingArgs &ra, uint32_t n_frames)
     const dim3 grid((uint32_t)n_wg * 4u), block(64); // one wave per workgroup, four per tile
     // heavy-first launch order (STEPTH_FLAG_HEAVY_FIRST): worth its three small launches only
     // when the search kernel runs many rounds of workgroups
+    const uint32_t *verdict = nullptr; // the scan kernel's: 1 = identity order, plain variant
     if (ra.heavy_first && n_wg >= 8192u && !e->stats_enabled) { // (a 1080p frame has 8228)
         TileOrderBufs ob{};
         ob.n_wg = (uint32_t)n_wg;
@@ -429,15 +435,18 @@ int launch_tile(stepth_engine *e, const RingArgs &ra, uint32_t n_frames)
         ob.order = ob.off + (size_t)ob.n_groups * 16u + 32u; // (17 words of class bases in between)
         hipLaunchKernelGGL(tile_cost_kernel, dim3(ob.n_groups), dim3(1024), 0, e->stream, ta, ob);
         hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, e->stream, ob);
-        hipLaunchKernelGGL(tile_scatter_kernel, dim3((uint32_t)((n_wg + 255u) / 256u)), dim3(256), 0, e->stream, ob);
+        hipLaunchKernelGGL(tile_scatter_kernel, dim3((uint32_t)((n_wg + 255u) / 256u)), dim3(256), 0, e->stream, ob, 0u);
         ta.order = ob.order;
+        verdict = ob.off + (size_t)ob.n_groups * 16u + 16u;
     }
     {
         KernelTimer t(e); // the dominant kernel (bench.py's roofline leg)
         // (STEPTH_FLAG_HEAVY_FIRST = natural images: the pooled-probe variant goes with the order)
         if (e->stats_enabled)
             hipLaunchKernelGGL((ring_tile_kernel<true, false>), grid, block, 0, e->stream, ta);
-        else if (ra.heavy_first)
+        else if (verdict)
+            hipLaunchKernelGGL(ring_tile_auto_kernel, grid, block, 0, e->stream, ta, verdict);
+        else if (ra.heavy_first) // (a small launch: no order, probe tasks all the same -- latency is all there is)
             hipLaunchKernelGGL((ring_tile_kernel<false, true>), grid, block, 0, e->stream, ta);
         else
             hipLaunchKernelGGL((ring_tile_kernel<false, false>), grid, block, 0, e->stream, ta);
@@ -543,7 +552,7 @@ int launch_list(stepth_engine *e, const RingArgs &ra, uint32_t n_frames, const P
         hipLaunchKernelGGL(list_cost_kernel, dim3((uint32_t)((n_waves + 3u) / 4u)), dim3(256), 0, e->stream, ca, ob);
         hipLaunchKernelGGL(list_rank_kernel, dim3(ob.n_groups), dim3(64), 0, e->stream, ob);
         hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, e->stream, ob);
-        hipLaunchKernelGGL(tile_scatter_kernel, dim3((uint32_t)((n_waves + 255u) / 256u)), dim3(256), 0, e->stream, ob);
+        hipLaunchKernelGGL(tile_scatter_kernel, dim3((uint32_t)((n_waves + 255u) / 256u)), dim3(256), 0, e->stream, ob, 1u);
         la.order = ob.order;
     }
     {
@@ -1128,7 +1137,7 @@ static int single_dense(stepth_engine *e, SingleCall &c)
     (void)main_im, (void)add_im, (void)H, (void)rp, (void)d_main, (void)ms, (void)as, (void)raw_only;
     // one group per pixel
     uint32_t bw = 0, bh = 0;
-    uint32_t lo = 0, hi = 0xFFFFFFFFu;
+    uint32_t lo = 0, hi = 0xFFFFFFFFu, col_hi = 0xFFFFFFFFu;
     if (p.max_steps < 0x40000000u) {
         // rows of the additional image the strip's searches can reach: the centres lie in
         // rows [row0/2, (row1+1)/2], every search stays within max_steps-1 rings of its centre
@@ -1136,11 +1145,12 @@ static int single_dense(stepth_engine *e, SingleCall &c)
         const uint32_t c_lo = row0 / 2u, c_hi = (row1 + 1u) / 2u;
         lo = c_lo > reach ? c_lo - reach : 0u;
         hi = c_hi + reach + 1u;
+        col_hi = (W + 1u) / 2u + reach + 1u;
     }
     // the dense lane = query search (tile_kernels.h); beyond 263 rings the round-1 trio
     const bool use_tile = tile_search_fits(p.max_steps, add_im->width, add_im->height);
     if (use_tile)
-        TRY(pack_additional_tiles(e, 1, &d_add, as, add_im->width, add_im->height, bw, bh, lo, hi));
+        TRY(pack_additional_tiles(e, 1, &d_add, as, add_im->width, add_im->height, bw, bh, lo, hi, col_hi));
     else
         TRY(pack_additional(e, 1, &d_add, as, add_im->width, add_im->height, bw, bh, lo, hi));
 
@@ -1457,16 +1467,24 @@ static int ring_queries_batch(stepth_engine *e, uint32_t nf, const stepth_image 
     const uint8_t *d_adds[kMaxBatch];
     for (uint32_t f = 0; f < nf; ++f)
         d_adds[f] = static_cast<const uint8_t *>(adds[f].data);
-    uint32_t bw = 0, bh = 0, lo = 0, hi = 0xFFFFFFFFu;
-    if (!d_groups && p.max_steps < 0x40000000u) { // rows the tiles' searches can reach
+    uint32_t bw = 0, bh = 0, lo = 0, hi = 0xFFFFFFFFu, col_hi = 0xFFFFFFFFu;
+    if (!d_groups && p.max_steps < 0x40000000u) { // rows and columns the tiles' searches can reach
         const uint32_t reach = p.max_steps ? p.max_steps - 1u : 0u;
         const uint32_t c_lo = row0 / 2u, c_hi = (row1 + p.tile_h) / 2u;
         lo = c_lo > reach ? c_lo - reach : 0u;
         hi = c_hi + reach + 1u;
+        col_hi = (W + p.tile_w) / 2u + reach + 1u;
+    } else if (late_counts && p.max_steps < 0x40000000u) {
+        // the engine's own groups (adaptive flow) lie inside the main image: x + w <= W, y + h <= H.
+        // A caller's list may hold anything: everything is packed for it.
+        const uint32_t reach = p.max_steps ? p.max_steps - 1u : 0u;
+        lo = row0 / 2u > reach ? row0 / 2u - reach : 0u; // (a group's top row lies in the strip, its bottom anywhere)
+        hi = H / 2u + reach + 1u;
+        col_hi = W / 2u + reach + 1u;
     }
     const bool use_list = tile_search_fits(p.max_steps, adds[0].width, adds[0].height);
     if (use_list)
-        TRY(pack_additional_tiles(e, nf, d_adds, adds[0].stride, adds[0].width, adds[0].height, bw, bh, lo, hi));
+        TRY(pack_additional_tiles(e, nf, d_adds, adds[0].stride, adds[0].width, adds[0].height, bw, bh, lo, hi, col_hi));
     else
         TRY(pack_additional(e, nf, d_adds, adds[0].stride, adds[0].width, adds[0].height, bw, bh, lo, hi));
     if (late_counts) {
@@ -1738,16 +1756,17 @@ int stepth_depth_from_additional_batch(stepth_engine *e, uint32_t n_frames,
         const uint8_t *d_adds[kMaxBatch];
         for (uint32_t f = 0; f < nf; ++f)
             d_adds[f] = static_cast<const uint8_t *>(adds[f0 + f].data);
-        uint32_t bw = 0, bh = 0, lo = 0, hi = 0xFFFFFFFFu;
+        uint32_t bw = 0, bh = 0, lo = 0, hi = 0xFFFFFFFFu, col_hi = 0xFFFFFFFFu;
         if (p.max_steps < 0x40000000u) { // rows of the additional image the searches can reach
             const uint32_t reach = p.max_steps ? p.max_steps - 1u : 0u;
             lo = row0 / 2u > reach ? row0 / 2u - reach : 0u;
             hi = (row1 + 1u) / 2u + reach + 1u;
+            col_hi = (W + 1u) / 2u + reach + 1u;
         }
         const bool use_tile = tile_search_fits(p.max_steps, adds[0].width, adds[0].height);
         if (use_tile)
             TRY(pack_additional_tiles(e, nf, d_adds, adds[0].stride, adds[0].width, adds[0].height,
-                                      bw, bh, lo, hi));
+                                      bw, bh, lo, hi, col_hi));
         else
             TRY(pack_additional(e, nf, d_adds, adds[0].stride, adds[0].width, adds[0].height, bw, bh,
                                 lo, hi));

@@ -79,6 +79,20 @@ __device__ __forceinline__ uint32_t rfl(uint32_t v)
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
 }
 
+// Half a row of block bounds (4 x {max, min} = 32 bytes) into scalar registers.  Written out
+// as the instruction: the compiler selects s_load for a plain load only while it can prove the
+// table unmodified since kernel entry, and loses that proof to a store, a fence or a second
+// code path elsewhere in the kernel.  The wait is part of it -- the compiler's
+// own counter bookkeeping does not see the load.
+typedef uint64_t u64x4 __attribute__((ext_vector_type(4)));
+template <int BYTE_OFFSET>
+__device__ __forceinline__ u64x4 sload_half_row(const void *p)
+{
+    u64x4 v;
+    asm("s_load_dwordx8 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&s"(v) : "s"(p), "n"(BYTE_OFFSET));
+    return v;
+}
+
 // Four block-bound tests (one half of a row of 8 blocks), highest column first, shifted into
 // `acc` (bit = column): four VALU instructions per block (tile_lane.h bound_bit), the bounds
 // straight from the scalar registers the s_load left them in.  b0 = the lowest column.
@@ -129,8 +143,8 @@ constexpr uint32_t kPoolCap = 128, kPoolFlushMin = 16;
 // <= 80 SGPRs keep 8 workgroups of 256 threads resident per CU (MI355X_MICROARCH.md,
 // "Residency": 800 / (sgprs + 16)); the kernel wants 106, the spills to vector lanes cost less
 // than the eighth wave per SIMD brings (1.28 -> 1.22 ms; 96: 1.23, 64: 1.24)
-template <bool STATS, bool POOL = false>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void ring_tile_kernel(TileArgs a)
+template <bool STATS, bool POOL>
+__device__ __forceinline__ void ring_tile_body(const TileArgs &a, const uint32_t *order)
 {
     // POOL: per wave the queries as the probe tasks see them, and the task pool
     __shared__ uint2 s_box[1][POOL ? 64 : 1];           // colour box {lo, hi}
@@ -153,7 +167,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void ring_
     // (1.16 -> 1.02 ms on the bench frames).  The workgroups an XCD runs at one time are still
     // neighbours in a row and read the same cells through its L2.
     const uint32_t tb = (blockIdx.x & 7u) + 8u * (blockIdx.x >> 5); // the tile's place in the launch order
-    const uint32_t bid = a.order ? a.order[tb] : tb;
+    const uint32_t bid = order ? order[tb] : tb;
     const uint32_t xcd = bid & 7u, xi = bid >> 3;
     const uint32_t g = xcd + 8u * (xi / a.cbx_n); // row of centre blocks, all frames stacked
     if (g >= a.n_rows)
@@ -392,13 +406,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void ring_
                         return acc << 8;
                     const ulonglong4 *rp4 = reinterpret_cast<const ulonglong4 *>(win + (size_t)row * a.bwp);
                     if (need_h) {
-                        const ulonglong4 v1 = rp4[1];
+                        const u64x4 v1 = sload_half_row<32>(rp4);
                         acc = test_half_row(acc, v1.x, v1.y, v1.z, v1.w, kq);
                     } else {
                         acc <<= 4;
                     }
                     if (need_l) {
-                        const ulonglong4 v0 = rp4[0];
+                        const u64x4 v0 = sload_half_row<0>(rp4);
                         acc = test_half_row(acc, v0.x, v0.y, v0.z, v0.w, kq);
                     } else {
                         acc <<= 4;
@@ -560,6 +574,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void ring_
 #endif
         }
     }
+}
+
+template <bool STATS, bool POOL = false>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void ring_tile_kernel(TileArgs a)
+{
+    ring_tile_body<STATS, POOL>(a, a.order);
+}
+
+// STEPTH_FLAG_HEAVY_FIRST: both variants in one kernel, chosen by what tile_scan_kernel found out
+// about the frames (`verdict` = its word 16: 1 = no light majority, the order is the identity):
+// natural images run the pooled variant in the heavy-first order, frames like the synthetic ones
+// -- issue bound, where probe tasks cost 10 % -- the plain variant in image order.  The host
+// cannot know which without waiting for the device; a wave-uniform branch costs nothing.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void ring_tile_auto_kernel(TileArgs a, const uint32_t *verdict)
+{
+    if (verdict[0])
+        ring_tile_body<false, false>(a, nullptr);
+    else
+        ring_tile_body<false, true>(a, a.order);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -740,14 +773,19 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(TileOrderBufs o)
     }
 }
 
-__global__ __launch_bounds__(256) void tile_scatter_kernel(TileOrderBufs o)
+__global__ __launch_bounds__(256) void tile_scatter_kernel(TileOrderBufs o, uint32_t identity_too)
 {
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     if (t >= o.n_wg)
         return;
     const uint32_t *base = o.off + (size_t)o.n_groups * 16u;
+    if (base[16]) { // identity order: ring_tile_auto_kernel does not read it, the list search does
+        if (identity_too)
+            o.order[t] = t;
+        return;
+    }
     const uint32_t c = o.cls[t];
-    o.order[base[16] ? t : base[c] + o.off[(size_t)(t >> 6) * 16u + c] + o.rank[t]] = t;
+    o.order[base[c] + o.off[(size_t)(t >> 6) * 16u + c] + o.rank[t]] = t;
 }
 
 // Heavy-first order for ring_list_kernel: the same estimate per WAVE of 64 sorted queries (the

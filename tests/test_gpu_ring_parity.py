@@ -328,6 +328,48 @@ def test_strips_with_short_reach_pack_only_part_of_the_additional_image(engine, 
         assert max(maxes) == ref["max"]
 
 
+def test_short_reach_packs_only_the_reachable_columns(engine, oracle, asset):
+    """the centres lie in the left half of the additional image (middle = ((x+w)/2, (y+h)/2),
+    src/depth_image.rs:114-117): block columns beyond centre + reach are not packed and keep an
+    earlier image's cells and bounds, which must never show -- single call, batch, tiles, and
+    the adaptive flow (the engine's own groups; a caller's list gets everything packed)"""
+    import torch
+    from stepth_amd import synth
+    main, add = asset["main"][..., :3], asset["additional"][..., :3]
+    other = synth.stereo_pair(600, 400, 32, seed=98)[0]
+    m = torch.from_numpy(np.ascontiguousarray(main)).cuda()
+    a = torch.from_numpy(np.ascontiguousarray(add)).cuda()
+    o = torch.from_numpy(np.ascontiguousarray(other)).cuda()
+    for ms in (3, 16, 40, 90):
+        engine.depth_from_additional_batch([m, m], [o, o], P36, max_steps=255)  # poison everything
+        ref = oracle.depth_from_additional(main, add, P36, ms)
+        d, mx = engine.depth_from_additional(main, add, P36, max_steps=ms)
+        assert mx == ref["max"] and np.array_equal(d, ref["depth"]), ms
+        engine.depth_from_additional_batch([m, m], [o, o], P36, max_steps=255)
+        outs, mxs = engine.depth_from_additional_batch([m, m], [a, a], P36, max_steps=ms)
+        assert list(mxs) == [ref["max"]] * 2 and np.array_equal(outs[1].cpu().numpy(), ref["depth"]), ms
+        engine.depth_from_additional_batch([m, m], [o, o], P36, max_steps=255)
+        ref = oracle.depth_from_additional(main, add, P36, ms, (5, 3))
+        outs, mxs = engine.depth_from_additional_batch([m, m], [a, a], P36, max_steps=ms, tile=(5, 3))
+        assert list(mxs) == [ref["max"]] * 2 and np.array_equal(outs[0].cpu().numpy(), ref["depth"]), ms
+        engine.depth_from_additional_batch([m, m], [o, o], P36, max_steps=255)
+        groups = oracle.adaptive_groups(main, P36, 16, 0)
+        ref = oracle.depth_from_additional(main, add, P36, ms, groups=groups)
+        outs, mxs = engine.adaptive_depth_batch([m, m], [a, a], P36, max_steps=ms)
+        assert list(mxs) == [ref["max"]] * 2 and np.array_equal(outs[1].cpu().numpy(), ref["depth"]), ms
+        # a caller's list with centres in the right half (rectangles reaching past the image):
+        # everything is packed for it
+        g = np.zeros(3, oracle.GROUP_DTYPE)
+        g["x"], g["y"], g["w"], g["h"] = [500, 590, 10], [10, 300, 390], [600, 400, 900], [20, 90, 10]
+        g["value"] = [main[10, 500], main[300, 590], main[390, 10]]
+        engine.depth_from_additional_batch([m, m], [o, o], P36, max_steps=255)
+        want = oracle.match_groups(g, add, ms, P36)["raw"]
+        gd = torch.from_numpy(g.view(np.uint8).reshape(-1, 20).copy()).cuda()
+        outs, _ = engine.depth_from_groups_batch([m], [a], P36, [gd], [3], max_steps=ms, raw_only=True)
+        got = outs[0].cpu().numpy()
+        assert [int(got[10, 500]), int(got[300, 590]), int(got[390, 10])] == [int(v) for v in want], ms
+
+
 @pytest.mark.parametrize("tile,block", [((1, 1), 2), ((1, 1), 16), ((1, 1), 6), ((4, 4), 8), ((5, 2), 10)])
 def test_interleaved_row_blocks_compose_to_the_full_frame(engine, oracle, tile, block):
     """rank r of N owns row blocks r, r+N, ...: PASS 1 per rank, max over ranks, PASS 2 per
