@@ -50,8 +50,8 @@ def test_traffic_profile_names_the_kernels_the_headline_step_launches():
     # the one-group-per-pixel batch: pack (+ superblock fold), the dense search, paint; the
     # sharded flow bench.py drives normalises the strip's rows in a launch of its own
     launched = _launched_in(["pack_additional_tiles", "launch_tile"])
-    # (the heavy-first order's three kernels run only under STEPTH_FLAG_HEAVY_FIRST: not in the headline)
-    launched -= {"tile_cost_kernel", "tile_scan_kernel", "tile_scatter_kernel"}
+    # (the heavy-first order's three kernels and the two-variant search run only under STEPTH_FLAG_HEAVY_FIRST: not in the headline)
+    launched -= {"tile_cost_kernel", "tile_scan_kernel", "tile_scatter_kernel", "ring_tile_auto_kernel"}
     assert launched == {"tile_pack_kernel", "tile_super_kernel", "ring_tile_kernel"}, launched
     assert launched <= profiled, f"profile lacks {launched - profiled}: re-run tools/run_profiles.sh"
     # per-launch means are over the headline step's launches only: every kernel of the step shows
