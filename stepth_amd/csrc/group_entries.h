@@ -20,7 +20,19 @@ static int adaptive_groups_device(stepth_engine *e, uint32_t nf, const uint8_t *
     const uint32_t seed_depth = std::min({min_splits, max_splits, 31u});
     if (!out)
         TRY(reserve(e, e->group_out, (size_t)px * sizeof(GroupRec) * nf));
-    for (int k = 0; k < 3; ++k)
+    // adaptive_tree_kernel (no node lists): 16-bit coordinates, subtrees of at most kTreeLevels levels
+    bool one_launch = W <= 0xFFFFu && H <= 0xFFFFu;
+    uint32_t levels = 0; // levels below the seed depth
+    {
+        uint32_t w = W, h = H; // the largest node of a depth: always the ceiling half
+        for (uint32_t d = 0; d < max_splits && (uint64_t)w * h > 1; ++d) {
+            (w >= h ? w : h) -= (w >= h ? w : h) / 2u;
+            levels += d >= seed_depth;
+        }
+        one_launch = one_launch && levels <= kTreeLevels;
+        levels = std::max(levels, 1u);
+    }
+    for (int k = 0; k < 3 && !one_launch; ++k)
         TRY(reserve(e, e->group_list[k], (size_t)px * sizeof(GroupNode) * nf));
     TRY(reserve(e, e->group_counters, 16 * kGroupCtrPad * kMaxBatch));
     AdaptiveArgs a{};
@@ -43,6 +55,12 @@ static int adaptive_groups_device(stepth_engine *e, uint32_t nf, const uint8_t *
     a.counters = static_cast<uint32_t *>(e->group_counters.p);
     HIP_TRY(e, hipMemsetAsync(a.counters, 0, 16 * kGroupCtrPad * nf, e->stream));
     const uint64_t seeds = 1ull << seed_depth;
+    if (one_launch) { // the whole tree below the seeds in one launch
+        hipLaunchKernelGGL(adaptive_tree_kernel, dim3((uint32_t)std::min<uint64_t>((seeds + 255) / 256, 4096), nf),
+                           dim3(256), levels * kTreeLevelCap * sizeof(uint2), e->stream, a, levels);
+        HIP_TRY(e, hipGetLastError());
+        return STEPTH_OK;
+    }
     hipLaunchKernelGGL(adaptive_seed_kernel,
                        dim3((uint32_t)std::min<uint64_t>((seeds + 255) / 256, 4096), nf), dim3(256), 0,
                        e->stream, a);

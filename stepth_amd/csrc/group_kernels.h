@@ -61,116 +61,120 @@ template <typename T> __device__ __forceinline__ void wave_append(bool yes, T *a
         arr[base + __popcll(m & ((1ull << lane) - 1ull))] = v;
 }
 
-// statistics of a rectangle -> leaf? ; writes the group or the two children
-__device__ __forceinline__ void adaptive_visit(const AdaptiveArgs &a, uint32_t f, bool live, GroupNode n,
-                                               uint32_t depth, GroupNode *next, uint32_t *next_count)
+// min / max / sum per channel over the rows y + sub, y + sub + nsub, ... of a rectangle (one lane's
+// share; nsub = 1: the whole rectangle)
+__device__ __forceinline__ void node_stats(const AdaptiveArgs &a, uint32_t f, const GroupNode &n, uint32_t sub,
+                                           uint32_t nsub, uint32_t (&mn)[3], uint32_t (&mx)[3],
+                                           unsigned long long (&total)[3])
 {
-    bool leaf = false;
     uint32_t sum[3] = {0, 0, 0};
-    GroupRec g{};
-    if (live) {
-        leaf = (uint64_t)n.w * n.h == 1 || depth >= a.max_splits;
-        if (leaf || depth >= a.min_splits) {
-            uint32_t mn[3] = {255, 255, 255}, mx[3] = {0, 0, 0};
-            unsigned long long s64[3] = {0, 0, 0};
-            // RGB8 rows that start on a 4-byte boundary are read a dword at a time (a byte load
-            // moves one byte per lane and instruction; the tree's rectangles are 7..8 x 4 pixels
-            // at the seed depth, 96 byte loads a thread).  Twelve bytes = four pixels = three
-            // dwords repeat the byte -> channel pattern, so the slots t[r], r = byte offset from
-            // the first dword mod 3, are static in the unrolled body; they are turned into
-            // channels once at the end (channel = (r + first dword's offset) mod 3).
-            const bool by_dwords = a.ch == 3u && ((reinterpret_cast<uintptr_t>(a.px[f]) | a.stride) & 3u) == 0u;
-            if (by_dwords) {
-                const uint32_t b0 = n.x * 3u, b1 = (n.x + n.w) * 3u, a0 = b0 & ~3u; // bytes of the row
-                const uint32_t row_bytes = a.W * 3u;
-                uint32_t tmn[3] = {255, 255, 255}, tmx[3] = {0, 0, 0}, tsum[3] = {0, 0, 0};
-                for (uint32_t yy = n.y; yy < n.y + n.h; ++yy) {
-                    const uint8_t *row = a.px[f] + (size_t)yy * a.stride;
-                    for (uint32_t o = a0; o < b1; o += 12u) {
-                        uint32_t dw[3]; // the three loads go out together
+    unsigned long long s64[3] = {0, 0, 0};
+    mn[0] = mn[1] = mn[2] = 255u;
+    mx[0] = mx[1] = mx[2] = 0u;
+    uint32_t rows_done = 0;
+    // RGB8 rows that start on a 4-byte boundary are read a dword at a time (a byte load
+    // moves one byte per lane and instruction).  Twelve bytes = four pixels = three
+    // dwords repeat the byte -> channel pattern, so the slots t[r], r = byte offset from
+    // the first dword mod 3, are static in the unrolled body; they are turned into
+    // channels once at the end (channel = (r + first dword's offset) mod 3).
+    const bool by_dwords = a.ch == 3u && ((reinterpret_cast<uintptr_t>(a.px[f]) | a.stride) & 3u) == 0u;
+    if (by_dwords) {
+        const uint32_t b0 = n.x * 3u, b1 = (n.x + n.w) * 3u, a0 = b0 & ~3u; // bytes of the row
+        const uint32_t row_bytes = a.W * 3u;
+        const uint32_t ph = a0 % 3u;
+        uint32_t tmn[3] = {255, 255, 255}, tmx[3] = {0, 0, 0}, tsum[3] = {0, 0, 0};
+        for (uint32_t yy = n.y + sub; yy < n.y + n.h; yy += nsub) {
+            const uint8_t *row = a.px[f] + (size_t)yy * a.stride;
+            for (uint32_t o = a0; o < b1; o += 12u) {
+                uint32_t dw[3]; // the three loads go out together
 #pragma unroll
-                        for (uint32_t i = 0; i < 3; ++i) {
-                            const uint32_t od = o + 4u * i;
-                            dw[i] = 0u;
-                            if (od + 4u <= row_bytes) { // whole dword inside the row
-                                if (od < b1)
-                                    dw[i] = *reinterpret_cast<const uint32_t *>(row + od);
-                            } else if (od < b1) { // the row's last bytes: never read past the image
-                                dw[i] = row[od];
-                                if (od + 1u < row_bytes)
-                                    dw[i] |= (uint32_t)row[od + 1u] << 8;
-                                if (od + 2u < row_bytes)
-                                    dw[i] |= (uint32_t)row[od + 2u] << 16;
-                            }
-                        }
-#pragma unroll
-                        for (uint32_t i = 0; i < 3; ++i)
-#pragma unroll
-                            for (uint32_t k = 0; k < 4; ++k) {
-                                const uint32_t od = o + 4u * i;
-                                const uint32_t r = (4u * i + k) % 3u, v = (dw[i] >> (8u * k)) & 0xffu;
-                                const bool in = od + k >= b0 && od + k < b1;
-                                tsum[r] += in ? v : 0u;
-                                tmn[r] = min(tmn[r], in ? v : 255u);
-                                tmx[r] = max(tmx[r], in ? v : 0u);
-                            }
-                    }
-                    if ((yy & 127u) == 127u) { // 128 rows x 65535 px x 255 still fit 32 bits
-                        const uint32_t ph = a0 % 3u;
-#pragma unroll
-                        for (int k = 0; k < 3; ++k) { // channel k sits in slot (k - ph) mod 3
-                            const uint32_t t = ph == 0u ? tsum[k] : ph == 1u ? tsum[(k + 2) % 3] : tsum[(k + 1) % 3];
-                            s64[k] += t;
-                        }
-                        tsum[0] = tsum[1] = tsum[2] = 0;
+                for (uint32_t i = 0; i < 3; ++i) {
+                    const uint32_t od = o + 4u * i;
+                    dw[i] = 0u;
+                    if (od + 4u <= row_bytes) { // whole dword inside the row
+                        if (od < b1)
+                            dw[i] = *reinterpret_cast<const uint32_t *>(row + od);
+                    } else if (od < b1) { // the row's last bytes: never read past the image
+                        dw[i] = row[od];
+                        if (od + 1u < row_bytes)
+                            dw[i] |= (uint32_t)row[od + 1u] << 8;
+                        if (od + 2u < row_bytes)
+                            dw[i] |= (uint32_t)row[od + 2u] << 16;
                     }
                 }
-                const uint32_t ph = a0 % 3u;
+#pragma unroll
+                for (uint32_t i = 0; i < 3; ++i)
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; ++k) {
+                        const uint32_t od = o + 4u * i;
+                        const uint32_t r = (4u * i + k) % 3u, v = (dw[i] >> (8u * k)) & 0xffu;
+                        const bool in = od + k >= b0 && od + k < b1;
+                        tsum[r] += in ? v : 0u;
+                        tmn[r] = min(tmn[r], in ? v : 255u);
+                        tmx[r] = max(tmx[r], in ? v : 0u);
+                    }
+            }
+            if ((++rows_done & 127u) == 0u) { // 128 rows x 65535 px x 255 still fit 32 bits
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { // channel k sits in slot (k - ph) mod 3
+                    const uint32_t t = ph == 0u ? tsum[k] : ph == 1u ? tsum[(k + 2) % 3] : tsum[(k + 1) % 3];
+                    s64[k] += t;
+                }
+                tsum[0] = tsum[1] = tsum[2] = 0;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            sum[k] = ph == 0u ? tsum[k] : ph == 1u ? tsum[(k + 2) % 3] : tsum[(k + 1) % 3];
+            mn[k] = ph == 0u ? tmn[k] : ph == 1u ? tmn[(k + 2) % 3] : tmn[(k + 1) % 3];
+            mx[k] = ph == 0u ? tmx[k] : ph == 1u ? tmx[(k + 2) % 3] : tmx[(k + 1) % 3];
+        }
+    } else {
+        for (uint32_t yy = n.y + sub; yy < n.y + n.h; yy += nsub) {
+            const uint8_t *p = a.px[f] + (size_t)yy * a.stride + (size_t)n.x * a.ch;
+            for (uint32_t xx = 0; xx < n.w; ++xx, p += a.ch) {
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
-                    sum[k] = ph == 0u ? tsum[k] : ph == 1u ? tsum[(k + 2) % 3] : tsum[(k + 1) % 3];
-                    mn[k] = ph == 0u ? tmn[k] : ph == 1u ? tmn[(k + 2) % 3] : tmn[(k + 1) % 3];
-                    mx[k] = ph == 0u ? tmx[k] : ph == 1u ? tmx[(k + 2) % 3] : tmx[(k + 1) % 3];
-                }
-            } else {
-                for (uint32_t yy = n.y; yy < n.y + n.h; ++yy) {
-                    const uint8_t *p = a.px[f] + (size_t)yy * a.stride + (size_t)n.x * a.ch;
-                    for (uint32_t xx = 0; xx < n.w; ++xx, p += a.ch) {
-#pragma unroll
-                        for (int k = 0; k < 3; ++k) {
-                            const uint32_t v = p[k];
-                            sum[k] += v;
-                            mn[k] = min(mn[k], v);
-                            mx[k] = max(mx[k], v);
-                        }
-                    }
-                    if ((yy & 127u) == 127u) { // 128 rows x 65535 px x 255 still fit 32 bits
-#pragma unroll
-                        for (int k = 0; k < 3; ++k) {
-                            s64[k] += sum[k];
-                            sum[k] = 0;
-                        }
-                    }
+                    const uint32_t v = p[k];
+                    sum[k] += v;
+                    mn[k] = min(mn[k], v);
+                    mx[k] = max(mx[k], v);
                 }
             }
-            if (!leaf)
-                leaf = mx[0] - mn[0] < a.prec[0] && mx[1] - mn[1] < a.prec[1] && mx[2] - mn[2] < a.prec[2];
-            if (leaf) {
-                const unsigned long long area = (unsigned long long)n.w * n.h;
-                g.x = n.x;
-                g.y = n.y;
-                g.w = n.w;
-                g.h = n.h;
+            if ((++rows_done & 127u) == 0u) { // 128 rows x 65535 px x 255 still fit 32 bits
 #pragma unroll
-                for (int k = 0; k < 3; ++k)
-                    g.value[k] = (uint8_t)((s64[k] + sum[k]) / area);
-                g.pad = 0;
+                for (int k = 0; k < 3; ++k) {
+                    s64[k] += sum[k];
+                    sum[k] = 0;
+                }
             }
         }
     }
-    wave_append(live && leaf, a.groups[f], &a.counters[4u * f * kGroupCtrPad], g);
-    const bool split = live && !leaf;
-    GroupNode c0 = n, c1 = n;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        total[k] = s64[k] + sum[k];
+}
+
+__device__ __forceinline__ GroupRec leaf_group(const GroupNode &n, const unsigned long long (&total)[3])
+{
+    GroupRec g{};
+    const unsigned long long area = (unsigned long long)n.w * n.h;
+    g.x = n.x;
+    g.y = n.y;
+    g.w = n.w;
+    g.h = n.h;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        g.value[k] = (uint8_t)(total[k] / area);
+    g.pad = 0;
+    return g;
+}
+
+// the two halves of a node: cut across its longer side into floor and ceiling halves
+__device__ __forceinline__ void split_node(const GroupNode &n, GroupNode &c0, GroupNode &c1)
+{
+    c0 = n;
+    c1 = n;
     if (n.w >= n.h) {
         c0.w = n.w / 2;
         c1.x = n.x + c0.w;
@@ -180,6 +184,30 @@ __device__ __forceinline__ void adaptive_visit(const AdaptiveArgs &a, uint32_t f
         c1.y = n.y + c0.h;
         c1.h = n.h - c0.h;
     }
+}
+
+// statistics of a rectangle -> leaf? ; writes the group or the two children
+__device__ __forceinline__ void adaptive_visit(const AdaptiveArgs &a, uint32_t f, bool live, GroupNode n,
+                                               uint32_t depth, GroupNode *next, uint32_t *next_count)
+{
+    bool leaf = false;
+    GroupRec g{};
+    if (live) {
+        leaf = (uint64_t)n.w * n.h == 1 || depth >= a.max_splits;
+        if (leaf || depth >= a.min_splits) {
+            uint32_t mn[3], mx[3];
+            unsigned long long total[3];
+            node_stats(a, f, n, 0u, 1u, mn, mx, total);
+            if (!leaf)
+                leaf = mx[0] - mn[0] < a.prec[0] && mx[1] - mn[1] < a.prec[1] && mx[2] - mn[2] < a.prec[2];
+            if (leaf)
+                g = leaf_group(n, total);
+        }
+    }
+    wave_append(live && leaf, a.groups[f], &a.counters[4u * f * kGroupCtrPad], g);
+    const bool split = live && !leaf;
+    GroupNode c0, c1;
+    split_node(n, c0, c1);
     // both children of a node end up adjacent
     const unsigned long long m = __ballot(split);
     if (m) {
@@ -196,35 +224,146 @@ __device__ __forceinline__ void adaptive_visit(const AdaptiveArgs &a, uint32_t f
     }
 }
 
-// one thread per node index of depth `seed_depth`: bit (seed_depth-1-d) of the index picks the
-// child at depth d.  A path that reaches a single pixel early belongs to the index whose
-// remaining bits are all zero.
+// the path from the root to node `i` of depth `seed_depth`: bit (seed_depth-1-d) of the index
+// picks the child at depth d.  A path that reaches a single pixel early belongs to the index
+// whose remaining bits are all zero.  Returns whether the node exists.
+__device__ __forceinline__ bool seed_node(const AdaptiveArgs &a, uint64_t i, GroupNode &n, uint32_t &depth)
+{
+    bool live = i < (1ull << a.seed_depth);
+    n = GroupNode{0, 0, a.W, a.H};
+    depth = 0;
+    for (; live && depth < a.seed_depth; ++depth) {
+        if ((uint64_t)n.w * n.h == 1) {
+            live = (i & ((1ull << (a.seed_depth - depth)) - 1ull)) == 0; // the all-zero suffix owns it
+            break;
+        }
+        const bool second = (i >> (a.seed_depth - 1 - depth)) & 1ull;
+        if (n.w >= n.h) {
+            const uint32_t w0 = n.w / 2;
+            n.x += second ? w0 : 0;
+            n.w = second ? n.w - w0 : w0;
+        } else {
+            const uint32_t h0 = n.h / 2;
+            n.y += second ? h0 : 0;
+            n.h = second ? n.h - h0 : h0;
+        }
+    }
+    return live;
+}
+
+// The whole tree below the seed depth in ONE launch (round 3; the seed + level launches below
+// remain for seeds whose subtrees are deeper than kTreeLevels and images wider than 65535).
+// A workgroup takes 256 seed nodes, one per thread, and keeps the nodes below them in LDS, one
+// array per level: a go pops up to 256 nodes of the DEEPEST level that has any (a thread per
+// node, as in the level launches: every lane busy), appends the leaves to the frame's groups
+// (one global atomic per workgroup and go) and pushes the halves of the others one level down.
+// Deepest first keeps every level at <= 512 nodes: a level is only fed (<= 2 x 256) by a pop of
+// the level above, which happens only when it and everything deeper is empty.
+// Tried first and slower than the six launches: four lanes per node with a stack per seed walked
+// depth first (a wave sits through its unluckiest seed's subtree: 5 x), and with one stack per
+// wave (3 x: a quad per node leaves most lanes idle on the small nodes deep in the tree).
+constexpr uint32_t kTreeLevels = 8, kTreeLevelCap = 512;
+
+__global__ __launch_bounds__(256) void adaptive_tree_kernel(AdaptiveArgs a, uint32_t levels)
+{
+    extern __shared__ uint2 s_level[]; // [levels][kTreeLevelCap] {x | y << 16, w | h << 16}; level l = depth seed + 1 + l
+    __shared__ uint32_t s_cnt[kTreeLevels];
+    __shared__ uint32_t s_leaves[2], s_base[2]; // by the parity of the go
+    const uint32_t f = blockIdx.y, t = threadIdx.x, lane = t & 63u;
+    if (t < kTreeLevels)
+        s_cnt[t] = 0u;
+    if (t < 2u)
+        s_leaves[t] = 0u;
+    const uint64_t total_seeds = 1ull << a.seed_depth;
+    const uint64_t rounds = (total_seeds + (uint64_t)gridDim.x * 256 - 1) / ((uint64_t)gridDim.x * 256);
+    uint32_t par = 0;
+    for (uint64_t r = 0; r < rounds; ++r) {
+        bool seeds = true; // the round's first go takes the seed nodes
+        // (a node leaves the levels for good or moves one level down: <= 2 x levels x 256-node
+        // pops per seed go; the guard only keeps a logic error from hanging the GPU)
+        for (uint32_t guard = 0; guard < 64u * kTreeLevels; ++guard) {
+            __syncthreads(); // the pushes of the last go
+            bool have;
+            GroupNode n{0, 0, 1, 1};
+            uint32_t depth, to = 0;
+            if (seeds) {
+                have = seed_node(a, (r * gridDim.x + blockIdx.x) * 256 + t, n, depth);
+                seeds = false;
+            } else {
+                int l = (int)levels - 1;
+                while (l >= 0 && s_cnt[l] == 0u)
+                    --l;
+                if (l < 0)
+                    break;
+                const uint32_t cnt = s_cnt[l], take = min(cnt, 256u);
+                have = t < take;
+                if (have) {
+                    const uint2 pn = s_level[(uint32_t)l * kTreeLevelCap + cnt - take + t];
+                    n = GroupNode{pn.x & 0xffffu, pn.x >> 16, pn.y & 0xffffu, pn.y >> 16};
+                }
+                __syncthreads();
+                if (t == 0)
+                    s_cnt[l] = cnt - take;
+                depth = a.seed_depth + 1u + (uint32_t)l;
+                // (level l + 1 exists whenever a node of level l can split: the host sized `levels`)
+                to = min((uint32_t)l + 1u, levels - 1u);
+            }
+            // ---- the go: the thread's node -> a leaf into the groups or two halves into level `to`
+            bool leaf = false;
+            GroupRec g{};
+            if (have) {
+                leaf = n.w * n.h == 1u || depth >= a.max_splits;
+                if (leaf || depth >= a.min_splits) {
+                    uint32_t mn[3], mx[3];
+                    unsigned long long total[3];
+                    node_stats(a, f, n, 0u, 1u, mn, mx, total);
+                    if (!leaf)
+                        leaf = mx[0] - mn[0] < a.prec[0] && mx[1] - mn[1] < a.prec[1] && mx[2] - mn[2] < a.prec[2];
+                    if (leaf)
+                        g = leaf_group(n, total);
+                }
+            }
+            const bool is_leaf = have && leaf, split = have && !leaf;
+            const unsigned long long ml = __ballot(is_leaf), ms = __ballot(split);
+            uint32_t leaf_at = 0, push_at = 0;
+            if (lane == 0) {
+                if (ml)
+                    leaf_at = atomicAdd(&s_leaves[par], (uint32_t)__popcll(ml));
+                if (ms)
+                    push_at = atomicAdd(&s_cnt[to], 2u * (uint32_t)__popcll(ms));
+            }
+            leaf_at = __shfl(leaf_at, 0) + (uint32_t)__popcll(ml & ((1ull << lane) - 1ull));
+            push_at = __shfl(push_at, 0) + 2u * (uint32_t)__popcll(ms & ((1ull << lane) - 1ull));
+            if (split) {
+                GroupNode c0, c1;
+                split_node(n, c0, c1);
+                s_level[to * kTreeLevelCap + push_at] = make_uint2(c0.x | (c0.y << 16), c0.w | (c0.h << 16));
+                s_level[to * kTreeLevelCap + push_at + 1u] = make_uint2(c1.x | (c1.y << 16), c1.w | (c1.h << 16));
+            }
+            __syncthreads();
+            if (t == 0) {
+                const uint32_t nl = s_leaves[par];
+                s_base[par] = nl ? atomicAdd(&a.counters[4u * f * kGroupCtrPad], nl) : 0u;
+                s_leaves[par ^ 1u] = 0u; // (the next go's; this one's is read no more)
+            }
+            __syncthreads();
+            if (is_leaf)
+                a.groups[f][s_base[par] + leaf_at] = g;
+            par ^= 1u;
+        }
+    }
+}
+
+// one thread per node index of depth `seed_depth` (seed_node)
 __global__ __launch_bounds__(256) void adaptive_seed_kernel(AdaptiveArgs a)
 {
     const uint32_t f = blockIdx.y;
     const uint64_t total = 1ull << a.seed_depth;
     const uint64_t rounds = (total + (uint64_t)gridDim.x * 256 - 1) / ((uint64_t)gridDim.x * 256);
     for (uint64_t r = 0; r < rounds; ++r) { // whole waves stay together for the ballots
-        const uint64_t i = (r * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
-        bool live = i < total;
-        GroupNode n{0, 0, a.W, a.H};
-        uint32_t depth = 0;
-        for (; live && depth < a.seed_depth; ++depth) {
-            if ((uint64_t)n.w * n.h == 1) {
-                live = (i & ((1ull << (a.seed_depth - depth)) - 1ull)) == 0; // the all-zero suffix owns it
-                break;
-            }
-            const bool second = (i >> (a.seed_depth - 1 - depth)) & 1ull;
-            if (n.w >= n.h) {
-                const uint32_t w0 = n.w / 2;
-                n.x += second ? w0 : 0;
-                n.w = second ? n.w - w0 : w0;
-            } else {
-                const uint32_t h0 = n.h / 2;
-                n.y += second ? h0 : 0;
-                n.h = second ? n.h - h0 : h0;
-            }
-        }
+        GroupNode n;
+        uint32_t depth;
+        const bool live = seed_node(a, (r * gridDim.x + blockIdx.x) * 256 + threadIdx.x, n, depth);
         adaptive_visit(a, f, live, n, depth, a.list[(a.seed_depth + 1) % 3] + f * a.list_stride,
                        &a.counters[(4u * f + 1 + (a.seed_depth + 1) % 3) * kGroupCtrPad]);
     }
