@@ -44,6 +44,7 @@ struct SadArgs {
     // packed planes (sad_pack_kernel)
     uint32_t *lp, *rp;
     uint32_t lpitch, rpitch; // dwords
+    uint32_t cols, strips;   // sad_search_kernel: waves per strip, strips per frame (launch_sad)
 };
 
 __device__ __forceinline__ uint32_t load_rgbx(const uint8_t *img, size_t stride, uint32_t ch,
@@ -94,11 +95,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void sa
     __shared__ uint32_t s_best[1][kSadRows][64]; // running min cost
     __shared__ uint32_t s_pick[1][kSadRows][64]; // bit 31: decided (under threshold); low: d
     const int lane = threadIdx.x & 63, wv = 0;
-    const int x = (int)blockIdx.x * 64 + lane;                     // output column
-    const int ys = (int)a.row0 + (int)blockIdx.y * kSadRows;       // first output row
-    const int nrows = min(kSadRows, (int)a.row1 - ys);
-    if ((int)blockIdx.x * 64 >= (int)a.w) // whole wave outside (uniform)
+    // Workgroup ids go round-robin over the 8 XCDs, each with its own L2.  A wave reads the
+    // right image's columns [x - d_max - RAD, x + 64 + RAD): two thirds of what its left
+    // neighbour reads at d_max 128 -- so the waves of one strip belong on ONE XCD, one after the
+    // other in its dispatch order.  XCD k takes the strips k, k + 8, ... (frames stacked).
+    // (With blockIdx = (column, strip, frame) the neighbours sat on 8 different XCDs and every L2
+    // fetched the whole band for itself: 1.62 GB per 4 x 4K launch, 6 x the planes.)
+    const uint32_t xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
+    const uint32_t g = (j / a.cols) * 8u + xcd, bcol = j % a.cols; // strip of the stacked frames, its wave
+    if (g >= a.strips * a.n_frames)
         return;
+    const uint32_t f = g / a.strips; // frame
+    const int x = (int)bcol * 64 + lane;                                // output column
+    const int ys = (int)a.row0 + (int)(g - f * a.strips) * kSadRows;    // first output row
+    const int nrows = min(kSadRows, (int)a.row1 - ys);
 #pragma unroll
     for (int r = 0; r < kSadRows; ++r) {
         s_best[wv][r][lane] = 0xffffffffu;
@@ -106,7 +116,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void sa
     }
     // plane coordinates: image (x', y') sits at [y' - row0 + RAD][x' + apron_l] (the planes hold
     // only the rows the strip [row0, row1) reads)
-    const uint32_t f = blockIdx.z; // frame
     const uint32_t *lcol = a.lp + (size_t)f * a.lplane_stride + x; // + i  -> L(x - RAD + i)
     for (int d0 = 0; d0 < (int)a.d_max; d0 += DC) {
         // + k -> R(x - RAD + i - d) with k = i + (DC-1-j), d = d0 + j
@@ -216,8 +225,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void sa
     for (int o = 32; o > 0; o >>= 1)
         m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
     // (a plain read first: most waves cannot raise the max, and atomics on one line serialise)
-    if (lane == 0 && m > __hip_atomic_load(a.max_word + blockIdx.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-        atomicMax(a.max_word + blockIdx.z, m);
+    if (lane == 0 && m > __hip_atomic_load(a.max_word + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        atomicMax(a.max_word + f, m);
 }
 
 // ---- generic fallback (any odd window up to 15): one thread per pixel, windows in LDS ----
@@ -320,13 +329,17 @@ inline int launch_sad_pack(const SadArgs &a, hipStream_t stream)
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
-inline int launch_sad(const SadArgs &a, hipStream_t stream)
+inline int launch_sad(const SadArgs &a_in, hipStream_t stream)
 {
+    SadArgs a = a_in;
     if (sad_has_fast_path(a.win)) {
         const uint32_t cols = (a.w + 63) / 64, rows = a.row1 - a.row0; // one wave (64 columns) per workgroup
         // enough waves to fill 256 CUs x 12 wave slots with 16-row strips?
         const bool tall = (size_t)cols * ((rows + 15) / 16) * a.n_frames >= 6144;
-        const dim3 grid(cols, tall ? (rows + 15) / 16 : (rows + 7) / 8, a.n_frames);
+        a.cols = cols;
+        a.strips = tall ? (rows + 15) / 16 : (rows + 7) / 8;
+        // strips of all frames dealt to the 8 XCDs (see the kernel)
+        const dim3 grid((a.strips * a.n_frames + 7u) / 8u * 8u * cols);
 #define STEPTH_SAD_LAUNCH(W, D)                                                               \
     do {                                                                                      \
         if (tall)                                                                             \

@@ -957,6 +957,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     __shared__ uint32_t s_task[1][kListPoolCap]; // the pool: query lane | block x << 6 | block y << 19
     const uint32_t lane = threadIdx.x & 63u;
     constexpr uint32_t wv = 0;
+#ifdef STEPTH_LIST_PROFILE // tuning build: how long the waves run, and what the long ones do
+    [[maybe_unused]] const unsigned long long lp_t0 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
+    [[maybe_unused]] unsigned long long lp_goes = 0, lp_visits = 0, lp_go_ticks = 0, lp_m0_ticks = 0, lp_visit_ticks = 0, lp_survey_ticks = 0;
+#endif
     const uint32_t wid = a.order ? a.order[blockIdx.x] : blockIdx.x;
     const uint32_t f = wid / a.wpf;
     // a wave takes `lanes` (16, 32 or 64) consecutive queries: a small launch is bound by the
@@ -1014,6 +1018,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
             int ox = 0, oy = 0;   // the window's block (0,0), per lane
             int rounds = 1;
             if (mode == 0) {
+#ifdef STEPTH_LIST_PROFILE
+                const unsigned long long lp_w0 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
+#endif
                 // ---- the 7x7 blocks around the lane's own centre block (block-rings 0..3) ----
                 if (q.limit != 0u) {
                     if constexpr (STATS)
@@ -1036,8 +1043,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                     ox = cbx - 3;
                     oy = cby - 3;
                 }
+#ifdef STEPTH_LIST_PROFILE
+                if constexpr (STATS)
+                    lp_m0_ticks += __builtin_amdgcn_s_memtime() - lp_w0 + (cand & 1ull) * 0ull;
+#endif
                 rounds = 4;
             } else if (mode == 1) {
+#ifdef STEPTH_LIST_PROFILE
+                const unsigned long long lp_v0 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
+#define STEPTH_LP_VISIT_END() do { if constexpr (STATS) lp_visit_ticks += __builtin_amdgcn_s_memtime() - lp_v0; } while (0)
+#else
+#define STEPTH_LP_VISIT_END() ((void)0)
+#endif
                 // ---- the lanes still searching share what they can: the bounding box of their
                 // centres gives ONE window of superblocks for the wave, surveyed once and visited
                 // nearest first (bounds by scalar loads, every lane against its own box and its
@@ -1045,6 +1062,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                 const uint32_t pick = wave_min_dpp(min(min(skey0, skey1), skey2));
                 if (pick == kTileNoKey || (pick >> 8) >= wave_max_dpp(q.limit) + tol) {
                     mode = 3; // (limits only shrink when the pooled tasks run: the search stays over)
+                    STEPTH_LP_VISIT_END();
                     continue;
                 }
                 skey0 = skey0 == pick ? kTileNoKey : skey0;
@@ -1055,10 +1073,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                 const int ax = (sx << 6) - q.qx, ay = (sy << 6) - q.qy;
                 const uint32_t dS = (uint32_t)max(max(max(ax, -63 - ax), max(ay, -63 - ay)), 0);
                 const bool want = dS < q.limit && box_meets(sb.x, sb.y, q.lo, q.hi);
-                if (!__builtin_amdgcn_ballot_w64(want))
+                if (!__builtin_amdgcn_ballot_w64(want)) {
+                    STEPTH_LP_VISIT_END();
                     continue;
+                }
                 if constexpr (STATS)
                     n_super += want;
+#ifdef STEPTH_LIST_PROFILE
+                ++lp_visits;
+#endif
                 const int bx0 = sx * 8, by0 = sy * 8;
                 // bounds of the superblock's 64 blocks: rows and half rows beyond every lane's
                 // limit (distances from the box of the wave's centres) are skipped
@@ -1074,13 +1097,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                         return acc << 8;
                     const ulonglong4 *rp4 = reinterpret_cast<const ulonglong4 *>(win + (size_t)row * a.bwp);
                     if (need_h) {
-                        const ulonglong4 v1 = rp4[1];
+                        const u64x4 v1 = sload_half_row<32>(rp4);
                         acc = test_half_row(acc, v1.x, v1.y, v1.z, v1.w, kq);
                     } else {
                         acc <<= 4;
                     }
                     if (need_l) {
-                        const ulonglong4 v0 = rp4[0];
+                        const u64x4 v0 = sload_half_row<0>(rp4);
                         acc = test_half_row(acc, v0.x, v0.y, v0.z, v0.w, kq);
                     } else {
                         acc <<= 4;
@@ -1099,6 +1122,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                     cand = (((uint64_t)m_hi << 32) | m_lo) & ~window_le_mask(bx0, by0, cbx, cby, 3);
                 ox = bx0;
                 oy = by0;
+                STEPTH_LP_VISIT_END();
             } else if (mode == 2) {
                 // ---- spread-out wave: every lane walks the superblocks of its own window, ring
                 // by ring around its own superblock (the wave shares only the loop counters) ----
@@ -1194,7 +1218,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                         // intrinsic would turn the scalar loads of the bound rows into vector loads.)
                         s_best[wv][lane] = q.best; // what the lane knows of its own query
                         s_lim[wv][lane] = q.limit;
+#ifdef STEPTH_LIST_PROFILE
+                        const unsigned long long lp_g0 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
+#endif
                         for (uint32_t base = 0; base < n_pool; base += 64u) {
+#ifdef STEPTH_LIST_PROFILE
+                            ++lp_goes;
+#endif
                             const uint32_t ti = base + lane;
                             if (ti < n_pool) {
                                 const uint32_t t = s_task[wv][ti], src = t & 63u;
@@ -1229,6 +1259,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                             q.best = s_best[wv][lane];
                             q.limit = s_lim[wv][lane];
                         }
+#ifdef STEPTH_LIST_PROFILE
+                        if constexpr (STATS)
+                            lp_go_ticks += __builtin_amdgcn_s_memtime() - lp_g0;
+#endif
                     }
                     if (!more)
                         break;
@@ -1245,6 +1279,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                 // ---- far phase: one window for the wave if the lanes still searching lie close
                 // enough together for the 10 x 12 slots, else per-lane windows ----
                 const bool far = q.limit != 0u;
+#ifdef STEPTH_LIST_PROFILE
+                const unsigned long long lp_s0 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
+#endif
                 wx_lo = (int)wave_min_dpp(far ? (uint32_t)q.qx : 0x7fffffffu);
                 wy_lo = (int)wave_min_dpp(far ? (uint32_t)q.qy : 0x7fffffffu);
                 wx_hi = (int)wave_max_dpp(far ? (uint32_t)q.qx : 0u);
@@ -1298,9 +1335,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                     scx = q.qx >> 6;
                     scy = q.qy >> 6;
                 }
+#ifdef STEPTH_LIST_PROFILE
+                if constexpr (STATS)
+                    lp_survey_ticks += __builtin_amdgcn_s_memtime() - lp_s0;
+#endif
             }
         }
     }
+#ifdef STEPTH_LIST_PROFILE
+    [[maybe_unused]] const unsigned long long lp_e0 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
+#endif
 
     // ---- distance, store, max (depth_image.rs:118-124) ----
     uint32_t d = 0;
@@ -1360,6 +1404,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
             atomicAdd(&stats_replica(a.stats)[2], v2);
             atomicAdd(&stats_replica(a.stats)[4], v4);
             atomicAdd(&stats_replica(a.stats)[5], v5);
+#ifdef STEPTH_LIST_PROFILE
+            // waves by run time (s_memtime ticks of 10 ns): bucket b = log2(ticks) - 13 in 0..7 -- [8+b]
+            // waves, [16+b] their shared-window visits, [24+b] their goes
+            const unsigned long long ticks = __builtin_amdgcn_s_memtime() - lp_t0;
+            const int b = min(max(63 - __builtin_clzll(ticks | 1ull) - 13, 0), 7);
+            atomicAdd(&stats_replica(a.stats)[8 + b], 1ull);
+            if (b < 5)
+                atomicAdd(&stats_replica(a.stats)[16 + b], lp_visits);
+            atomicAdd(&stats_replica(a.stats)[24 + b], lp_goes);
+            atomicAdd(&stats_replica(a.stats)[6], ticks);
+            atomicAdd(&stats_replica(a.stats)[7], lp_go_ticks);
+            atomicAdd(&stats_replica(a.stats)[3], lp_m0_ticks);
+            // (this build only: the three words below replace the per-bucket visit sums of buckets 5..7)
+            atomicAdd(&stats_replica(a.stats)[21], lp_visit_ticks);
+            atomicAdd(&stats_replica(a.stats)[22], lp_survey_ticks);
+            atomicAdd(&stats_replica(a.stats)[23], lp_e0 - lp_t0);
+#endif
         }
     }
 }
