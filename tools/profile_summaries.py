@@ -30,7 +30,7 @@ DOMINANT = "ring_tile_kernel<false, false>"
 STEPS, WARMUP = 6, 2
 CMD = f"python bench.py --steps {STEPS} --warmup {WARMUP} --no-cpu-baseline --no-extra-legs"
 LEGS = {  # directory under the profile root -> (what ran, the kernel the leg is about)
-    "asset": ("python tools/leg_time.py asset 128 hf  (8 x 1080p natural frames, STEPTH_FLAG_HEAVY_FIRST: order + pooled probes)", "ring_tile_kernel<false, true>"),
+    "asset": ("python tools/leg_time.py asset 128 hf  (8 x 1080p natural frames, STEPTH_FLAG_HEAVY_FIRST: order + pooled probes, chosen on the device)", "ring_tile_auto_kernel"),
     "adaptive": ("python tools/leg_adaptive.py bench  (adaptive flow, 8 x 1080p synthetic)", "ring_list_kernel<false>"),
     "adaptive_asset": ("python tools/leg_adaptive.py asset  (adaptive flow, 8 x 1080p natural)", "ring_list_kernel<false>"),
     "sad": ("python tools/leg_sad.py  (windowed SAD 5x5, d_max 128, 4 x 3840x2160)", "sad_search_kernel<5, 16, 16>"),
