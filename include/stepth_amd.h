@@ -79,11 +79,11 @@ enum {
     /* ring mode, one group per pixel, for natural images (most pixels match nearby, a few
      * percent search far): the search's workgroups start heaviest first (a cheap estimate per
      * 16x16-pixel tile, three small extra launches; frame sets in which most tiles search far
-     * keep image order, decided on the device) and probe candidate blocks as pooled tasks, 64 at
-     * a time by whichever lanes.  Results are the same bit for bit.  The reference's own pair at
-     * 1080p: 8 frames 1.23 -> 0.92 ms per call, one frame 0.52 -> 0.30 ms; synthetic frames with
-     * large occlusions: + 14 %, which is why it is OFF by default in the C-ABI; the DepthImage
-     * mirrors of the reference API (photographs) set it. */
+     * keep image order and the plain search, decided on the device) and probe candidate blocks as
+     * pooled tasks, 64 at a time by whichever lanes.  Results are the same bit for bit.  The
+     * reference's own pair at 1080p: 8 frames 1.24 -> 0.91 ms per call, one frame 0.52 -> 0.30 ms;
+     * synthetic frames with large occlusions: + 5 % (the three launches), which is why it is OFF
+     * by default in the C-ABI; the DepthImage mirrors of the reference API (photographs) set it. */
     STEPTH_FLAG_HEAVY_FIRST = 1u << 3
 };
 
