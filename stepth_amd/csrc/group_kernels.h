@@ -279,9 +279,9 @@ __global__ __launch_bounds__(256) void adaptive_tree_kernel(AdaptiveArgs a, uint
     uint32_t par = 0;
     for (uint64_t r = 0; r < rounds; ++r) {
         bool seeds = true; // the round's first go takes the seed nodes
-        // (a node leaves the levels for good or moves one level down: <= 2 x levels x 256-node
-        // pops per seed go; the guard only keeps a logic error from hanging the GPU)
-        for (uint32_t guard = 0; guard < 64u * kTreeLevels; ++guard) {
+        // (every go takes at least one node out of the <= 256 (2^(levels+1) - 1) of a round: the
+        // guard is never reached, it only keeps a logic error from hanging the GPU)
+        for (uint32_t guard = 0; guard < (512u << levels); ++guard) {
             __syncthreads(); // the pushes of the last go
             bool have;
             GroupNode n{0, 0, 1, 1};

@@ -211,3 +211,21 @@ def test_long_reach_list_order_changes_nothing(engine, oracle, asset):
     ref = oracle.depth_from_additional(nat[0], nat[1], prec, 255, groups=oracle.adaptive_groups(nat[0], prec, 16, 0))
     assert ref["status"] == 0 and ma[1] == ref["max"]
     assert np.array_equal(a[1].cpu().numpy(), ref["depth"])
+
+
+@pytest.mark.gpu
+def test_deepest_trees_of_the_one_launch_grouping(engine, oracle):
+    """adaptive_tree_kernel at its limits: seeds of 16x16 pixels (8 levels below them) that all
+    split down to single pixels (noise, precision 1: 256 seeds x 511 nodes per workgroup, far
+    more gos than levels), the same with max_splits cutting the tree short, and one level more
+    (the seed + level launches take over)"""
+    rng = np.random.default_rng(7)
+    img = rng.integers(0, 256, (256, 256, 3), dtype=np.uint8)
+    img[64:128, :96] = 77  # and a flat patch: leaves at every depth
+    for prec, mn, mx in (([1] * 3, 8, 0), ([1] * 3, 8, 13), ([9, 1, 200], 9, 0), ([1] * 3, 7, 0), ([1] * 3, 6, 14)):
+        want = oracle.adaptive_groups(img, prec, mn, mx)
+        got = engine.adaptive_groups(img, prec, mn, mx)
+        got = np.ascontiguousarray(got).view(oracle.GROUP_DTYPE).ravel()
+        assert len(got) == len(want), (prec, mn, mx, len(got), len(want))
+        k = lambda g: g[np.lexsort((g["h"], g["w"], g["x"], g["y"]))]
+        assert (k(got) == k(np.ascontiguousarray(want))).all(), (prec, mn, mx)
