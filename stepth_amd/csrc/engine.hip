@@ -40,11 +40,11 @@ struct DevBuf {
 } // namespace
 
 // words: [0..63] max per frame of a batch (a single call uses [0]), [64] host max staged for
-// normalise_rows, [65] pending count, then from word 128 on the kParts run counters of
-// ring_search_kernel
-constexpr uint32_t kWordHostMax = 64, kWordPending = 65, kWordCounters = 128;
+// normalise_rows, then from word 128 on one counter per frame (the list search's queue of
+// rectangles too large for its own lanes to paint)
+constexpr uint32_t kWordHostMax = 64, kWordCounters = 128;
 constexpr size_t kStatsBytes = (size_t)kStatsWords * kStatsReplicas * 8; // replicated counters (ring_kernels.h)
-constexpr size_t kWordsBytes = (kWordCounters + kParts * kPartStride) * 4;
+constexpr size_t kWordsBytes = (kWordCounters + kMaxBatch) * 4;
 static_assert(kMaxBatch <= (int)kWordHostMax, "per-frame max words");
 
 struct stepth_engine {
@@ -53,12 +53,11 @@ struct stepth_engine {
     hipStream_t stream = nullptr;
     std::string err;
 
-    DevBuf T, BB, SB;      // packed additional image: tiled cells, block / superblock bounds
-    DevBuf TT, LB, BBp, SBp; // dense search (tile_kernels.h): column-major cells, line bounds, padded bounds
+    DevBuf T, TT, LB, BBp, SBp; // packed additional image: cells row- and column-major, line bounds, padded block / superblock bounds
     uint32_t bbp_layout[3] = {0, 0, 0}; // bw, bh, frames the zero border of BBp was laid out for
     DevBuf stage_main, stage_add, stage_out, stage_groups;
     DevBuf queries_sorted, query_ids, query_bins; // group lists sorted by search-centre bin
-    DevBuf queries, raw, aux32, aux_pos, aux_found, pending, pending_rec, pending_key;
+    DevBuf queries, raw, aux32, aux_pos, aux_found, pending;
     DevBuf sad_left, sad_right, gauss_tmp, gauss_io;
     DevBuf zone_counts, zone_tables; // depth_split: 256 counts and one ZoneTable per frame
     DevBuf group_out, group_list[3], group_counters; // adaptive grouping (group_entries.h)
@@ -70,8 +69,6 @@ struct stepth_engine {
                ev_out[2] = {nullptr, nullptr};
     uint32_t *words = nullptr; // layout: kWord* above
     unsigned long long *stats = nullptr; // [ring0_hits, probes]
-    DevBuf spiral;                       // block-spiral table + per-chunk complete rings
-    uint32_t spiral_chunks = 0;
     uint64_t stats_groups = 0;
     bool stats_enabled = false;
 
@@ -228,59 +225,13 @@ struct KernelTimer { // brackets the dominant kernel with events when timing is 
 };
 
 
-// RGB8 additional image -> tiled cells T + block bounds BB (src/depth_image.rs:96-100)
-// Also clears the engine's words (max, pending count, run counters) for the kernels that
-// follow: one launch less than a memset.
-int pack_additional(stepth_engine *e, uint32_t n_frames, const uint8_t *const *d_adds,
-                    size_t stride, uint32_t wa, uint32_t ha, uint32_t &bw, uint32_t &bh,
-                    uint32_t row_lo = 0, uint32_t row_hi = 0xFFFFFFFFu)
-{
-    bw = (wa + 7u) / 8u;
-    bh = (ha + 7u) / 8u;
-    const size_t nblk = (size_t)bw * bh;
-    if (nblk * 64 * n_frames > 0x3FFFFFFFull) // kernels index cells with 32-bit byte offsets
-        return fail(e, STEPTH_ERR_BAD_ARG, "additional image %ux%u x %u frames exceeds 2^30 cells",
-                    wa, ha, n_frames);
-    const uint32_t sbw = (bw + 7u) / 8u, sbh = (bh + 7u) / 8u;
-    TRY(reserve(e, e->T, nblk * 64 * 4 * n_frames));
-    TRY(reserve(e, e->BB, nblk * 8 * n_frames));
-    TRY(reserve(e, e->SB, (size_t)sbw * sbh * 8 * n_frames));
-    // only the cell rows [row_lo,row_hi) can be reached by the searches of this call
-    row_hi = std::min(row_hi, ha);
-    row_lo = std::min(row_lo, row_hi);
-    const uint32_t by0 = row_lo / 8u, by1 = std::max((row_hi + 7u) / 8u, by0 + 1u);
-    PackArgs pa{};
-    for (uint32_t f = 0; f < n_frames; ++f)
-        pa.src[f] = d_adds[f];
-    pa.stride = stride;
-    pa.wa = wa;
-    pa.ha = ha;
-    pa.bw = bw;
-    pa.bh = bh;
-    pa.T = (uint32_t *)e->T.p;
-    pa.BB = (uint2 *)e->BB.p;
-    pa.by0 = by0;
-    pa.nby = std::min(by1, bh) - by0;
-    pa.zero = e->words;
-    pa.n_zero = (uint32_t)(kWordsBytes / 4);
-    pa.t_stride = (uint32_t)(nblk * 64);
-    pa.bb_stride = (uint32_t)nblk;
-    hipLaunchKernelGGL(pack_additional_kernel, dim3((bw * pa.nby + 3u) / 4u, n_frames), dim3(256),
-                       0, e->stream, pa);
-    SuperArgs sa{(const uint2 *)e->BB.p, bw, bh, sbw, sbh, (uint2 *)e->SB.p, by0 / 8u,
-                 (by0 + pa.nby + 7u) / 8u - by0 / 8u, by0, by0 + pa.nby, (uint32_t)nblk,
-                 sbw * sbh};
-    hipLaunchKernelGGL(pack_super_kernel, dim3((sbw * sa.nsby + 3u) / 4u, n_frames), dim3(256), 0,
-                       e->stream, sa);
-    HIP_TRY(e, hipGetLastError());
-    return STEPTH_OK;
-}
-
-// The dense search (tile_kernels.h) serves one group per pixel when the search fits its
-// superblock slots: rings up to 263 (the reference searches 255, depth_image.rs:119).
+// The dense search (tile_kernels.h) serves one group per pixel when the search fits its 10 x 10
+// superblock slots: rings up to 263 (the reference searches 255, depth_image.rs:119).  Beyond
+// that one group per pixel runs as 1x1 tiles of the prepared-query search, whose per-lane ring
+// walk has no such limit.
 bool tile_search_fits(uint32_t max_steps, uint32_t wa, uint32_t ha)
 {
-    return ((std::min(max_steps, std::max(wa, ha)) + 6u) >> 3) <= kSpiralRings;
+    return ((std::min(max_steps, std::max(wa, ha)) + 6u) >> 3) <= 33u;
 }
 
 // RGB8 additional images -> T, TT, padded block bounds, superblock bounds (tile_kernels.h)
@@ -566,156 +517,6 @@ int launch_list(stepth_engine *e, const RingArgs &ra, uint32_t n_frames, const P
     return STEPTH_OK;
 }
 
-// Block-spiral table of ring_match_kernel (query independent): enough chunks for the rings a
-// search of `max_steps` steps can reach in an array of wa x ha cells.
-int ensure_spiral(stepth_engine *e, uint32_t max_steps, uint32_t wa, uint32_t ha)
-{
-    const uint32_t s_cap = std::min(max_steps, std::max(wa, ha));
-    const uint32_t m_cap = (s_cap + 6u) >> 3;
-    const uint64_t slots = (uint64_t)(2 * m_cap + 1) * (2 * m_cap + 1);
-    const uint32_t chunks = std::max<uint32_t>((uint32_t)((slots + 63) / 64), kSpiralChunks);
-    if (chunks <= e->spiral_chunks)
-        return STEPTH_OK;
-    std::vector<uint32_t> tab((size_t)chunks * 65, 0u);
-    for (uint32_t u = 0; u < chunks * 64; ++u) {
-        int bi = 0, bj = 0;
-        block_slot(u, bi, bj);
-        tab[u] = ((uint32_t)bi & 0xffffu) | ((uint32_t)bj << 16);
-    }
-    for (uint32_t k = 0; k < chunks; ++k)
-        tab[(size_t)chunks * 64 + k] = rings_done(64u * (k + 1));
-    TRY(reserve(e, e->spiral, tab.size() * 4));
-    HIP_TRY(e, hipMemcpyAsync(e->spiral.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice,
-                              e->stream));
-    HIP_TRY(e, hipStreamSynchronize(e->stream)); // `tab` dies at return
-    e->spiral_chunks = chunks;
-    return STEPTH_OK;
-}
-
-// The round-1 search (ring_kernels.h: ring0_kernel -> ring_search_kernel -> ring_finish_kernel, one
-// WAVE per <= 4 queries, a block spiral): everything the lane = query kernels of tile_kernels.h
-// do not take -- searches of more than 265 rings.  ra.n = queries per frame (QMODE 1: the largest
-// of ra.nq[f])
-int launch_legacy_search(stepth_engine *e, RingArgs &ra, int qmode, uint32_t n_frames = 1)
-{
-    if (ra.n == 0)
-        return STEPTH_OK;
-    const uint32_t slots = qmode == 0 ? ra.n_slots : ra.n;
-    if (slots == 0) // a row pattern can leave a rank without rows
-        return STEPTH_OK;
-    // few queries (a short group list, a thin strip): smaller workgroups, so that every CU gets one
-    const bool small_launch = (uint64_t)slots * n_frames < (1u << 20);
-    const uint32_t r0_iters = small_launch ? kRing0ItersSmall : kRing0Iters;
-    const uint32_t blocks = (slots + 256u * r0_iters - 1u) / (256u * r0_iters);
-    TRY(ensure_spiral(e, ra.max_steps, ra.wa, ra.ha));
-    {
-        // 32-bit scan keys: ring | side(2) | position; sized for the farthest reachable ring
-        const uint32_t top = std::max(std::min(ra.max_steps, std::max(ra.wa, ra.ha)), 2u) - 1u;
-        uint32_t pb = 1, rb = 1;
-        while ((2u * top) >> pb)
-            ++pb;
-        while (top >> rb)
-            ++rb;
-        if (pb + 2u + rb > 32u)
-            return fail(e, STEPTH_ERR_BAD_ARG,
-                        "max_steps %u on a %ux%u array needs rings beyond 16383: unsupported",
-                        ra.max_steps, ra.wa, ra.ha);
-        ra.pos_bits = pb;
-    }
-    ra.spiral = (const uint32_t *)e->spiral.p;
-    ra.spiral_done = ra.spiral + (size_t)e->spiral_chunks * 64;
-    const size_t n_all = (size_t)ra.n * n_frames;
-    ra.id_bits = n_frames > 1 ? 26u : 32u; // callers batch only frames of <= 2^26 queries
-    if (n_frames > 1 && ra.n > (1u << 26))
-        return fail(e, STEPTH_ERR_BAD_ARG, "batch of frames with more than 2^26 queries each");
-    TRY(reserve(e, e->pending, n_all * 4));
-    ra.pending = (uint32_t *)e->pending.p;
-    TRY(reserve(e, e->pending_rec, n_all * sizeof(Query)));
-    ra.pending_rec = (Query *)e->pending_rec.p;
-    ra.pending_count = e->words + kWordPending;
-    ra.pending_next = e->words + kWordCounters;
-    ra.stats = e->stats_enabled ? e->stats : nullptr;
-    TRY(reserve(e, e->pending_key, n_all * 4));
-    const uint32_t nblk = ra.bw * ra.bh;
-    ra.t_stride = nblk * 64u;
-    ra.raw_stride = (uint32_t)((ra.n + 3u) & ~3u);
-
-    SearchArgs sa{};
-    sa.T = ra.T;
-    sa.BB = ra.BB;
-    sa.SB = ra.SB;
-    sa.rec = ra.pending_rec;
-    sa.key = (uint32_t *)e->pending_key.p;
-    sa.count = ra.pending_count;
-    sa.next = ra.pending_next;
-    sa.spiral = ra.spiral;
-    sa.spiral_done = ra.spiral_done;
-    sa.stats = ra.stats;
-    sa.wa = ra.wa;
-    sa.ha = ra.ha;
-    sa.bw = ra.bw;
-    sa.bh = ra.bh;
-    sa.sbw = ra.sbw;
-    sa.max_steps = ra.max_steps;
-    sa.pos_bits = ra.pos_bits;
-    sa.t_stride = ra.t_stride;
-    sa.bb_stride = nblk;
-    sa.sb_stride = ra.sbw * ra.sbh;
-
-    FinishArgs fa{};
-    fa.pending = ra.pending;
-    fa.rec = ra.pending_rec;
-    fa.key = sa.key;
-    fa.count = ra.pending_count;
-    fa.pos_bits = ra.pos_bits;
-    fa.id_bits = ra.id_bits;
-    fa.raw = ra.raw;
-    fa.raw32 = ra.raw32;
-    fa.pos = ra.pos;
-    fa.found = ra.found;
-    fa.max_word = ra.max_word;
-    fa.raw_stride = ra.raw_stride;
-
-    // search waves pull runs of queries from counters, so any grid works; 8 workgroups of 4
-    // waves per CU is the most that can be resident
-    const uint32_t search_blocks = (uint32_t)std::min<size_t>(2048u, (n_all + 63u) / 64u);
-    const uint32_t finish_blocks = (uint32_t)std::min<size_t>(1024u, (n_all + 255u) / 256u);
-    // block-rings a search can reach; the near + superblock scheme covers 33 of them
-    const bool far_search =
-        ((std::min(ra.max_steps, std::max(ra.wa, ra.ha)) + 6u) >> 3) > kSpiralRings;
-    const bool st = e->stats_enabled;
-    {
-        const dim3 g0(blocks, n_frames), b0(256);
-#define STEPTH_RING0(Q, S, I) hipLaunchKernelGGL((ring0_kernel<Q, S, I>), g0, b0, 0, e->stream, ra)
-        if (qmode == 0 && small_launch) {
-            if (st) STEPTH_RING0(0, true, kRing0ItersSmall); else STEPTH_RING0(0, false, kRing0ItersSmall);
-        } else if (qmode == 0) {
-            if (st) STEPTH_RING0(0, true, kRing0Iters); else STEPTH_RING0(0, false, kRing0Iters);
-        } else if (small_launch) {
-            if (st) STEPTH_RING0(1, true, kRing0ItersSmall); else STEPTH_RING0(1, false, kRing0ItersSmall);
-        } else {
-            if (st) STEPTH_RING0(1, true, kRing0Iters); else STEPTH_RING0(1, false, kRing0Iters);
-        }
-#undef STEPTH_RING0
-    }
-    {
-    KernelTimer t(e); // the dominant kernel only (bench.py's roofline leg)
-    if (far_search) {
-        if (st)
-            hipLaunchKernelGGL((ring_search_kernel<true, true>), dim3(search_blocks), dim3(256), 0, e->stream, sa);
-        else
-            hipLaunchKernelGGL((ring_search_kernel<false, true>), dim3(search_blocks), dim3(256), 0, e->stream, sa);
-    } else {
-        if (st)
-            hipLaunchKernelGGL((ring_search_kernel<true, false>), dim3(search_blocks), dim3(256), 0, e->stream, sa);
-        else
-            hipLaunchKernelGGL((ring_search_kernel<false, false>), dim3(search_blocks), dim3(256), 0, e->stream, sa);
-    }
-    }
-    hipLaunchKernelGGL(ring_finish_kernel, dim3(finish_blocks), dim3(256), 0, e->stream, fa);
-    HIP_TRY(e, hipGetLastError());
-    return STEPTH_OK;
-}
 
 // image::imageops::sample::gaussian(x, 0.5) and the per-border-class tap weights of a
 // same-size resample (support 3): taps with offsets cl-3 .. 3-cr, normalised by their sum
@@ -873,9 +674,9 @@ void stepth_engine_destroy(stepth_engine *e)
         return;
     (void)hipSetDevice(e->device);
     (void)hipStreamSynchronize(e->stream);
-    for (DevBuf *b : {&e->T, &e->BB, &e->SB, &e->TT, &e->LB, &e->BBp, &e->SBp, &e->spiral, &e->stage_main, &e->stage_add, &e->stage_out,
+    for (DevBuf *b : {&e->T, &e->TT, &e->LB, &e->BBp, &e->SBp, &e->stage_main, &e->stage_add, &e->stage_out,
                       &e->stage_groups, &e->queries, &e->queries_sorted, &e->query_ids, &e->query_bins, &e->raw, &e->aux32, &e->aux_pos,
-                      &e->aux_found, &e->pending, &e->pending_rec, &e->pending_key, &e->sad_left, &e->sad_right, &e->gauss_tmp, &e->gauss_io,
+                      &e->aux_found, &e->pending, &e->sad_left, &e->sad_right, &e->gauss_tmp, &e->gauss_io,
                       &e->zone_counts, &e->zone_tables, &e->pipe_main[0], &e->pipe_main[1],
                       &e->pipe_add[0], &e->pipe_add[1], &e->pipe_out[0], &e->pipe_out[1], &e->pipe_max, &e->group_out,
                       &e->group_list[0], &e->group_list[1], &e->group_list[2], &e->group_counters, &e->order_bytes, &e->order_words})
@@ -1120,8 +921,9 @@ static int single_prepared(stepth_engine *e, SingleCall &c, const stepth_group *
     return STEPTH_OK;
 }
 
-// one group per pixel: the dense lane = query search (tile_kernels.h); beyond 265 rings the
-// round-1 search (launch_legacy_search)
+// one group per pixel: the dense lane = query search (tile_kernels.h).  (Beyond its reach --
+// more than 263 rings; the reference always searches 255 -- the caller goes to single_prepared
+// with 1x1 tiles.)
 static int single_dense(stepth_engine *e, SingleCall &c)
 {
     const stepth_params &p = c.p;
@@ -1147,17 +949,10 @@ static int single_dense(stepth_engine *e, SingleCall &c)
         hi = c_hi + reach + 1u;
         col_hi = (W + 1u) / 2u + reach + 1u;
     }
-    // the dense lane = query search (tile_kernels.h); beyond 263 rings the round-1 trio
-    const bool use_tile = tile_search_fits(p.max_steps, add_im->width, add_im->height);
-    if (use_tile)
-        TRY(pack_additional_tiles(e, 1, &d_add, as, add_im->width, add_im->height, bw, bh, lo, hi, col_hi));
-    else
-        TRY(pack_additional(e, 1, &d_add, as, add_im->width, add_im->height, bw, bh, lo, hi));
+    TRY(pack_additional_tiles(e, 1, &d_add, as, add_im->width, add_im->height, bw, bh, lo, hi, col_hi));
 
     RingArgs ra{};
     ra.T = (const uint32_t *)e->T.p;
-    ra.BB = (const uint2 *)e->BB.p;
-    ra.SB = (const uint2 *)e->SB.p;
     ra.sbw = (bw + 7u) / 8u;
     ra.sbh = (bh + 7u) / 8u;
     ra.wa = add_im->width;
@@ -1175,21 +970,7 @@ static int single_dense(stepth_engine *e, SingleCall &c)
     ra.w = W;
     ra.row0 = row0;
     ra.row1 = row1;
-    // (round-1 trio) 2x2 tiles anchored at odd coordinates: tile (tx,ty) = pixels 2tx-1..2tx x
-    // 2ty-1..2ty, all of which have middle (tx,ty)
-    ra.ntx = (W >> 1) + 1u;
-    ra.ty0 = (row0 + 1u) >> 1;
-    uint64_t n_slots = rows ? (uint64_t)ra.ntx * ((row1 >> 1) - ra.ty0 + 1u) * 4u : 0u;
     ra.rp = rp;
-    if (rp.block) {
-        // owned blocks b = rem, rem+mod, ... with b*block < H
-        const uint32_t nb_all = (H + rp.block - 1u) / rp.block;
-        const uint32_t nb = nb_all > rp.rem ? (nb_all - rp.rem + rp.mod - 1u) / rp.mod : 0u;
-        n_slots = rows ? (uint64_t)ra.ntx * nb * (rp.block / 2u + 1u) * 4u : 0u;
-    }
-    if (n_slots > 0xFFFFFFFFull && !use_tile)
-        return fail(e, STEPTH_ERR_BAD_ARG, "%ux%u pixels: too many query slots for one call", W, rows);
-    ra.n_slots = (uint32_t)std::min<uint64_t>(n_slots, 0xFFFFFFFFull);
     TRY(reserve(e, e->raw, std::max<size_t>(ra.n, 4)));
     ra.raw = static_cast<uint8_t *>(e->raw.p);
     if (e->stats_enabled) {
@@ -1197,10 +978,7 @@ static int single_dense(stepth_engine *e, SingleCall &c)
         e->stats_groups = ra.n;
     }
     ra.heavy_first = (p.flags & STEPTH_FLAG_HEAVY_FIRST) != 0;
-    if (use_tile)
-        TRY(launch_tile(e, ra, 1));
-    else
-        TRY(launch_legacy_search(e, ra, 0));
+    TRY(launch_tile(e, ra, 1));
 
     if (rows) {
         PaintArgs pa{};
@@ -1305,8 +1083,9 @@ int stepth_depth_from_additional(stepth_engine *e, const stepth_image *main_im,
     SingleCall c{p, main_im, add_im, W, H, row0, row1, rp, async, raw_only, d_main, d_add, ms, as, os, d_out, max_out, false};
     if (p.mode == STEPTH_MODE_SAD_WINDOW)
         TRY(single_sad(e, c, groups));
-    else if (p.mode == STEPTH_MODE_RING_FIRST_HIT && (groups || p.tile_w != 1 || p.tile_h != 1))
-        TRY(single_prepared(e, c, groups, n_groups, groups_memory));
+    else if (p.mode == STEPTH_MODE_RING_FIRST_HIT &&
+             (groups || p.tile_w != 1 || p.tile_h != 1 || !tile_search_fits(p.max_steps, add_im->width, add_im->height)))
+        TRY(single_prepared(e, c, groups, n_groups, groups_memory)); // (1x1 tiles beyond the dense search's reach too)
     else if (p.mode == STEPTH_MODE_RING_FIRST_HIT)
         TRY(single_dense(e, c));
     else
@@ -1482,11 +1261,7 @@ static int ring_queries_batch(stepth_engine *e, uint32_t nf, const stepth_image 
         hi = H / 2u + reach + 1u;
         col_hi = W / 2u + reach + 1u;
     }
-    const bool use_list = tile_search_fits(p.max_steps, adds[0].width, adds[0].height);
-    if (use_list)
-        TRY(pack_additional_tiles(e, nf, d_adds, adds[0].stride, adds[0].width, adds[0].height, bw, bh, lo, hi, col_hi));
-    else
-        TRY(pack_additional(e, nf, d_adds, adds[0].stride, adds[0].width, adds[0].height, bw, bh, lo, hi));
+    TRY(pack_additional_tiles(e, nf, d_adds, adds[0].stride, adds[0].width, adds[0].height, bw, bh, lo, hi, col_hi));
     if (late_counts) {
         TRY(late_counts(e, nf, late_buf));
         n_groups = late_buf;
@@ -1494,8 +1269,6 @@ static int ring_queries_batch(stepth_engine *e, uint32_t nf, const stepth_image 
 
     RingArgs ra{};
     ra.T = (const uint32_t *)e->T.p;
-    ra.BB = (const uint2 *)e->BB.p;
-    ra.SB = (const uint2 *)e->SB.p;
     ra.sbw = (bw + 7u) / 8u;
     ra.sbh = (bh + 7u) / 8u;
     ra.wa = adds[0].width;
@@ -1540,7 +1313,7 @@ static int ring_queries_batch(stepth_engine *e, uint32_t nf, const stepth_image 
     TRY(reserve(e, e->queries, (size_t)n_max * nf * sizeof(Query)));
     pr.out = (Query *)e->queries.p;
     const dim3 pgrid((n_max + 255) / 256, nf);
-    const bool sort_queries = d_groups && use_list; // tiles come in row-major order already
+    const bool sort_queries = d_groups != nullptr; // tiles come in row-major order already
     BinArgs ba{};
     if (sort_queries) {
         ba.bins_x = (adds[0].width + 31u) / 32u;
@@ -1613,11 +1386,8 @@ static int ring_queries_batch(stepth_engine *e, uint32_t nf, const stepth_image 
                            dim3(256), 0, e->stream, pa);
     }
     // group lists on the per-lane search: it paints the raw values itself, PASS 2 follows in place
-    const bool fused_paint = d_groups && use_list;
-    if (use_list)
-        TRY(launch_list(e, ra, nf, fused_paint ? &pa : nullptr));
-    else
-        TRY(launch_legacy_search(e, ra, 1, nf));
+    const bool fused_paint = d_groups != nullptr;
+    TRY(launch_list(e, ra, nf, fused_paint ? &pa : nullptr));
 
     if (fused_paint) {
         hipLaunchKernelGGL(paint_big_kernel, dim3(64, nf), dim3(256), 0, e->stream, pa,
@@ -1666,9 +1436,10 @@ int stepth_depth_from_additional_batch(stepth_engine *e, uint32_t n_frames,
     const bool sad = p.mode == STEPTH_MODE_SAD_WINDOW;
     if (!sad && (p.mode != STEPTH_MODE_RING_FIRST_HIT || p.tile_w == 0 || p.tile_h == 0))
         return fail(e, STEPTH_ERR_BAD_ARG, "batch: ring mode with uniform tiles or SAD mode");
-    const bool tiles = !sad && (p.tile_w != 1 || p.tile_h != 1);
+    // (beyond the dense search's reach one group per pixel is a 1x1 tile of the prepared-query search)
+    const bool tiles = !sad && (p.tile_w != 1 || p.tile_h != 1 || !tile_search_fits(p.max_steps, adds[0].width, adds[0].height));
     const bool gauss_tail = p.flags & STEPTH_FLAG_GAUSSIAN_TAIL;
-    if (gauss_tail && (sad || tiles || (p.flags & STEPTH_FLAG_RAW_ONLY) || p.row_block ||
+    if (gauss_tail && (sad || p.tile_w != 1 || p.tile_h != 1 || (p.flags & STEPTH_FLAG_RAW_ONLY) || p.row_block ||
                        !(p.row_begin == 0 && (p.row_end == 0 || p.row_end == mains[0].height))))
         return fail(e, STEPTH_ERR_BAD_ARG,
                     "STEPTH_FLAG_GAUSSIAN_TAIL needs whole normalised ring-mode frames");
@@ -1687,7 +1458,7 @@ int stepth_depth_from_additional_batch(stepth_engine *e, uint32_t n_frames,
             return fail(e, STEPTH_ERR_SIZE_MISMATCH, "Sizes don't match");
     }
     if (n_host == 3 * n_frames) { // every image in host memory: staged and pipelined
-        if (tiles)
+        if (!sad && (p.tile_w != 1 || p.tile_h != 1))
             return fail(e, STEPTH_ERR_BAD_ARG, "batch: host-memory frames take 1x1 tiles or the SAD mode");
         return batch_host(e, n_frames, mains, adds, p, depths, max_out);
     }
@@ -1738,6 +1509,12 @@ int stepth_depth_from_additional_batch(stepth_engine *e, uint32_t n_frames,
             const uint32_t nf = std::min<uint32_t>(chunk_t, n_frames - f0);
             TRY(ring_queries_batch(e, nf, mains + f0, adds + f0, tp, row0, row1, rp, nullptr, nullptr,
                                    depths + f0, max_out ? max_out + f0 : nullptr, any_zero));
+            if (gauss_tail) { // (one group per pixel beyond the dense search's reach; whole device frames)
+                uint8_t *outs[kMaxBatch];
+                for (uint32_t f = 0; f < nf; ++f)
+                    outs[f] = static_cast<uint8_t *>(const_cast<void *>(depths[f0 + f].data));
+                TRY(gaussian_device_batch(e, nf, outs, depths[f0].stride, W, H, outs, depths[f0].stride));
+            }
         }
         if (!async && any_zero && !raw_only)
             return fail(e, STEPTH_ERR_MAX_ZERO, "a frame's distances are all 0; its output is all zero");
@@ -1749,8 +1526,6 @@ int stepth_depth_from_additional_batch(stepth_engine *e, uint32_t n_frames,
     const uint64_t cells = (uint64_t)((adds[0].width + 7u) / 8u) * ((adds[0].height + 7u) / 8u) * 64u;
     uint32_t chunk = (uint32_t)std::max<uint64_t>(
         1, std::min<uint64_t>(kMaxBatch, 0x3FFFFFFFull / std::max<uint64_t>(cells, 1)));
-    if ((uint64_t)W * rows > (1ull << 26)) // the pending ids keep 6 bits for the frame
-        chunk = 1;
     for (uint32_t f0 = 0; f0 < n_frames; f0 += chunk) {
         const uint32_t nf = std::min<uint32_t>(chunk, n_frames - f0);
         const uint8_t *d_adds[kMaxBatch];
@@ -1763,18 +1538,11 @@ int stepth_depth_from_additional_batch(stepth_engine *e, uint32_t n_frames,
             hi = (row1 + 1u) / 2u + reach + 1u;
             col_hi = (W + 1u) / 2u + reach + 1u;
         }
-        const bool use_tile = tile_search_fits(p.max_steps, adds[0].width, adds[0].height);
-        if (use_tile)
-            TRY(pack_additional_tiles(e, nf, d_adds, adds[0].stride, adds[0].width, adds[0].height,
-                                      bw, bh, lo, hi, col_hi));
-        else
-            TRY(pack_additional(e, nf, d_adds, adds[0].stride, adds[0].width, adds[0].height, bw, bh,
-                                lo, hi));
+        TRY(pack_additional_tiles(e, nf, d_adds, adds[0].stride, adds[0].width, adds[0].height,
+                                  bw, bh, lo, hi, col_hi));
 
         RingArgs ra{};
         ra.T = (const uint32_t *)e->T.p;
-        ra.BB = (const uint2 *)e->BB.p;
-        ra.SB = (const uint2 *)e->SB.p;
         ra.sbw = (bw + 7u) / 8u;
         ra.sbh = (bh + 7u) / 8u;
         ra.wa = adds[0].width;
@@ -1791,15 +1559,7 @@ int stepth_depth_from_additional_batch(stepth_engine *e, uint32_t n_frames,
         ra.w = W;
         ra.row0 = row0;
         ra.row1 = row1;
-        ra.ntx = (W >> 1) + 1u;
-        ra.ty0 = (row0 + 1u) >> 1;
-        ra.n_slots = ra.ntx * ((row1 >> 1) - ra.ty0 + 1u) * 4u;
         ra.rp = rp;
-        if (rp.block) {
-            const uint32_t nb_all = (H + rp.block - 1u) / rp.block;
-            const uint32_t nb = nb_all > rp.rem ? (nb_all - rp.rem + rp.mod - 1u) / rp.mod : 0u;
-            ra.n_slots = ra.ntx * nb * (rp.block / 2u + 1u) * 4u;
-        }
         ra.n = W * rows;
         const size_t raw_stride = ((size_t)ra.n + 3u) & ~(size_t)3u;
         TRY(reserve(e, e->raw, raw_stride * nf));
@@ -1809,10 +1569,7 @@ int stepth_depth_from_additional_batch(stepth_engine *e, uint32_t n_frames,
             e->stats_groups = (uint64_t)ra.n * nf;
         }
         ra.heavy_first = (p.flags & STEPTH_FLAG_HEAVY_FIRST) != 0;
-        if (use_tile)
-            TRY(launch_tile(e, ra, nf));
-        else if (ra.n_slots)
-            TRY(launch_legacy_search(e, ra, 0, nf));
+        TRY(launch_tile(e, ra, nf));
 
         PaintArgs pa{};
         pa.raw = ra.raw;
@@ -2156,11 +1913,7 @@ int stepth_distance_dot_array_batch(stepth_engine *e, const stepth_image *array,
     size_t as = 0;
     TRY(to_device(e, *array, e->stage_add, d_add, as));
     uint32_t bw = 0, bh = 0;
-    const bool use_list = tile_search_fits(max, array->width, array->height);
-    if (use_list)
-        TRY(pack_additional_tiles(e, 1, &d_add, as, array->width, array->height, bw, bh, 0, 0xFFFFFFFFu));
-    else
-        TRY(pack_additional(e, 1, &d_add, as, array->width, array->height, bw, bh));
+    TRY(pack_additional_tiles(e, 1, &d_add, as, array->width, array->height, bw, bh, 0, 0xFFFFFFFFu));
 
     std::vector<Query> qs(n);
     for (size_t i = 0; i < n; ++i) {
@@ -2177,8 +1930,6 @@ int stepth_distance_dot_array_batch(stepth_engine *e, const stepth_image *array,
                               e->stream));
     RingArgs ra{};
     ra.T = (const uint32_t *)e->T.p;
-    ra.BB = (const uint2 *)e->BB.p;
-    ra.SB = (const uint2 *)e->SB.p;
     ra.sbw = (bw + 7u) / 8u;
     ra.sbh = (bh + 7u) / 8u;
     ra.wa = array->width;
@@ -2199,10 +1950,7 @@ int stepth_distance_dot_array_batch(stepth_engine *e, const stepth_image *array,
         HIP_TRY(e, hipMemsetAsync(e->stats, 0, kStatsBytes, e->stream));
         e->stats_groups = n;
     }
-    if (use_list)
-        TRY(launch_list(e, ra, 1));
-    else
-        TRY(launch_legacy_search(e, ra, 1));
+    TRY(launch_list(e, ra, 1));
     HIP_TRY(e, hipMemcpyAsync(dist, ra.raw32, n * 4, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipMemcpyAsync(pos_xy, ra.pos, n * 8, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipMemcpyAsync(found, ra.found, n, hipMemcpyDeviceToHost, e->stream));

@@ -11,18 +11,6 @@
 
 namespace stepth {
 
-// ---------------------------------------------------------------------------------------
-// pack_additional: RGB8 [Ha][Wa] -> the search structure in HBM.  Replaces
-// disage::converters::raw_rgb + pixels_to_array (src/depth_image.rs:97-100): instead of a
-// Vec<Vec<[u8;3]>> the additional image becomes
-//
-//   T  [bh][bw][8][8] dwords  cells (cell_pack.h) tiled in 8x8 blocks, one block = 256
-//                             contiguous bytes = one fully coalesced wave read; cells of
-//                             edge blocks that fall outside the image are kNoCell
-//   BB [bh][bw] uint2         per-block channel bounds {max, min} in the same spread format
-//
-// with bw = ceil(Wa/8), bh = ceil(Ha/8).  One wave packs one block.
-// ---------------------------------------------------------------------------------------
 constexpr int kMaxBatch = 64; // frames one set of launches can carry (blockIdx.y / record bits)
 
 // Statistic counters are kept in kStatsReplicas copies of kStatsWords words, a workgroup adds to
@@ -34,109 +22,6 @@ __device__ __forceinline__ unsigned long long *stats_replica(unsigned long long 
 {
     return base + (blockIdx.x % kStatsReplicas) * kStatsWords;
 }
-constexpr int kBlk = 8;       // block side
-constexpr int kBlkShift = 3;
-
-struct PackArgs {
-    const uint8_t *src[kMaxBatch]; // one additional image per frame (blockIdx.y)
-    size_t stride;
-    uint32_t wa, ha;
-    uint32_t bw, bh;
-    uint32_t *T;
-    uint2 *BB;
-    uint32_t by0, nby; // block rows to pack (a row strip only reaches part of the image)
-    uint32_t *zero;    // words to clear for the kernels that follow (max, counters) ...
-    uint32_t n_zero;   // ... instead of a separate memset launch
-    uint32_t t_stride, bb_stride; // per-frame strides of T (dwords) and BB (uint2)
-};
-
-__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-        v = min(v, (uint32_t)__shfl_xor((int)v, o, 64));
-    return v;
-}
-
-__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-        v = max(v, (uint32_t)__shfl_xor((int)v, o, 64));
-    return v;
-}
-
-__global__ __launch_bounds__(256) void pack_additional_kernel(PackArgs a)
-{
-    const uint32_t lane = threadIdx.x & 63u, f = blockIdx.y;
-    if (blockIdx.x == 0 && f == 0)
-        for (uint32_t i = threadIdx.x; i < a.n_zero; i += blockDim.x)
-            a.zero[i] = 0u;
-    const uint32_t idx = blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (idx >= a.bw * a.nby)
-        return;
-    const uint32_t bx = idx % a.bw, by = a.by0 + idx / a.bw;
-    const uint32_t blk = by * a.bw + bx;
-    const uint32_t x = bx * kBlk + (lane & 7u), y = by * kBlk + (lane >> 3);
-    uint32_t cell = kNoCell;
-    uint32_t mn[3] = {255u, 255u, 255u}, mx[3] = {0u, 0u, 0u};
-    if (x < a.wa && y < a.ha) {
-        const uint8_t *p = a.src[f] + (size_t)y * a.stride + (size_t)x * 3;
-        mn[0] = mx[0] = p[0];
-        mn[1] = mx[1] = p[1];
-        mn[2] = mx[2] = p[2];
-        cell = pack_cell(p[0], p[1], p[2]);
-    }
-    a.T[(size_t)f * a.t_stride + (size_t)blk * 64u + lane] = cell;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        mn[c] = wave_min_u32(mn[c]);
-        mx[c] = wave_max_u32(mx[c]);
-    }
-    if (lane == 0)
-        a.BB[(size_t)f * a.bb_stride + blk] =
-            make_uint2(pack_cell(mx[0], mx[1], mx[2]), pack_cell(mn[0], mn[1], mn[2]));
-}
-
-// Superblock bounds: one wave folds the bounds of 8x8 blocks (64x64 cells) into SB.
-struct SuperArgs {
-    const uint2 *BB;
-    uint32_t bw, bh, sbw, sbh;
-    uint2 *SB;
-    uint32_t sby0, nsby; // superblock rows to fold, and the block rows that are valid: blocks
-    uint32_t by0, by1;   // outside [by0,by1) hold stale bounds and are left out
-    uint32_t bb_stride, sb_stride; // per-frame strides (blockIdx.y = frame)
-};
-
-__global__ __launch_bounds__(256) void pack_super_kernel(SuperArgs a)
-{
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t idx = blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (idx >= a.sbw * a.nsby)
-        return;
-    const uint32_t sb = (a.sby0 + idx / a.sbw) * a.sbw + idx % a.sbw;
-    const uint32_t bx = (sb % a.sbw) * 8u + (lane & 7u), by = (sb / a.sbw) * 8u + (lane >> 3);
-    uint32_t mn[3] = {255u, 255u, 255u}, mx[3] = {0u, 0u, 0u};
-    if (bx < a.bw && by >= a.by0 && by < a.by1) {
-        const uint2 bb = a.BB[(size_t)blockIdx.y * a.bb_stride + (size_t)by * a.bw + bx];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            mx[c] = (bb.x >> (10 * c)) & 0xffu;
-            mn[c] = (bb.y >> (10 * c)) & 0xffu;
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        mn[c] = wave_min_u32(mn[c]);
-        mx[c] = wave_max_u32(mx[c]);
-    }
-    if (lane == 0)
-        a.SB[(size_t)blockIdx.y * a.sb_stride + sb] =
-            make_uint2(pack_cell(mx[0], mx[1], mx[2]), pack_cell(mn[0], mn[1], mn[2]));
-}
-
-// Rows a call owns inside [row_begin,row_end): all of them (block == 0), or every mod-th block
-// of `block` rows -- interleaved row blocks balance the data-dependent work between ranks.
 struct RowPattern {
     uint32_t block, mod, rem;
     __device__ __forceinline__ bool owns(uint32_t y) const
@@ -309,92 +194,41 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(BinArgs a)
 }
 
 // ---------------------------------------------------------------------------------------
-// PASS 1 (src/depth_image.rs:112-123) with helpers::distance_dot_array inlined: two kernels.
-//
-// The reference walks rings s = 0,1,2,.. around `middle` and, inside a ring, row y+s, row
-// y-s, column x+s, column x-s, each ascending (helpers.rs:26-31), and returns the first cell
-// inside the colour box.  Give every cell the key ring|side|position of that scan: the answer
-// is the matching cell with the smallest key, so cells may be examined in ANY order and most
-// of them need not be examined at all.
-//
-//   ring0_kernel   dense, one lane per query (blockIdx.y = frame of a batch): tests the centre cell (ring 0) -- on natural
-//                  images a large share of the queries ends here -- writes the result 0 for
-//                  every query and compacts the survivors into `pending` (one wave-aggregated
-//                  atomic per wave).
-//   ring_search_kernel   persistent waves, ONE query per wave at a time, queries dealt
-//                  round-robin (wave w takes pending[w], pending[w+NW], ..): the work per
-//                  query is wildly uneven (0.2 .. 30 steps), interleaving gives every wave
-//                  the same mix and keeps all concurrently running waves inside one narrow
-//                  band of the image (L2 locality).  The 8x8 blocks around the centre block
-//                  are visited along a square spiral, 64 blocks per step (one lane each,
-//                  offsets from an LDS-staged table, bounds prefetched one step ahead); a
-//                  block whose channel bounds BB miss the colour box cannot hold a match and
-//                  is dropped after one 8-byte read -- 1/64 of the reference's probes.  Every
-//                  surviving block costs one step: 64 lanes read its 64 cells (256 contiguous
-//                  bytes, two blocks in flight), test them and, only if some cell matched,
-//                  compute keys and keep the smallest.
-//                  All cells of rings s <= 8 M lie in block-rings <= M, so once block-rings
-//                  0..M are done and the best key's ring is <= 8 M no unvisited cell can beat
-//                  it: stop.  Blocks whose nearest cell lies beyond the best ring are skipped.
-//
-// A ring search ends at the first ring with no in-bounds cell (helpers.rs:49-51): ring
-// max(cx, Wa-1-cx, cy, Ha-1-cy)+1 for an in-bounds centre, and immediately (None) for a
-// centre outside the array -- both folded into s_end.
+// What the host hands to the searches of tile_kernels.h (launch_tile: one group per pixel;
+// launch_list: prepared queries).  The reference walks rings s = 0,1,2,.. around `middle` and,
+// inside a ring, row y+s, row y-s, column x+s, column x-s, each ascending (helpers.rs:26-31),
+// and returns the first cell inside the colour box; with the key ring|side|position of that
+// scan the answer is the matching cell with the smallest key (tile_lane.h).  A ring search ends
+// at the first ring with no in-bounds cell (helpers.rs:49-51): ring max(cx, Wa-1-cx, cy,
+// Ha-1-cy)+1 for an in-bounds centre, and immediately (None) for a centre outside the array.
+// (The round-1 kernels -- ring0 / ring_search / ring_finish, one wave per <= 4 queries walking a
+// block spiral -- lived here until round 3; every reach now runs on the lane = query kernels.)
 // ---------------------------------------------------------------------------------------
 struct RingArgs {
     const uint32_t *T;
-    const uint2 *BB;
-    const uint2 *SB; // superblock (8x8 blocks) bounds, [sbh][sbw]
     uint32_t wa, ha, bw, bh, sbw, sbh;
-    // QMODE 0: one query per main pixel (uniform 1x1 tiles), read straight from the image;
-    // one image per frame (blockIdx.y)
+    // one query per main pixel (launch_tile), read straight from the image; one image per frame
     const uint8_t *main_px[kMaxBatch];
     size_t mstride;
     uint32_t mch, w, row0, row1;
-    uint32_t ntx, ty0, n_slots; // 2x2 tiles of the strip: columns, first tile row, slots
-    RowPattern rp;              // with a pattern: slots walk the owned row blocks only
-    // QMODE 1: prepared queries, frame f's at queries + f * q_stride, nq[f] of them
+    RowPattern rp;
+    // prepared queries (launch_list), frame f's at queries + f * q_stride, nq[f] of them
     const Query *queries;
     uint32_t q_stride;
     uint32_t nq[kMaxBatch];
-    uint32_t n; // queries per frame (QMODE 1: the largest nq[f])
-    const uint32_t *query_ids; // optional (ring_list_kernel): queries are sorted, results go to these slots
+    uint32_t n; // queries per frame (prepared: the largest nq[f])
+    const uint32_t *query_ids; // optional: queries are sorted, results go to these slots
     uint32_t max_steps;
-    uint32_t id_bits; // pending ids: query id in the low id_bits, frame above (32: one frame)
     uint8_t prec[3];
     uint8_t *raw;      // n: (d as u8), depth_image.rs:121
     uint32_t *raw32;   // optional: d
     uint32_t *pos;     // optional: winning cell (x,y)
     uint8_t *found;    // optional: Some/None
     uint32_t *max_word; // atomicMax of raw, depth_image.rs:124
-    unsigned long long *stats; // optional [ring0_hits, probes]
-    const uint32_t *spiral;      // block-spiral slots, spiral_chunks*64 entries (host-built)
-    const uint32_t *spiral_done; // per chunk k: complete block-rings after slots [0,64(k+1))
-    uint32_t pos_bits;           // key layout, see scan_key
-    uint32_t *pending;           // n: ids of the queries that missed at ring 0 (compacted by
-                                 // ring0_kernel), and their records {cx,cy,lo,hi}
-    Query *pending_rec;
-    uint32_t *pending_count;     // 1 word, zeroed before ring0_kernel
-    uint32_t *pending_next;      // kParts counters kPartStride words apart, zeroed: runs handed out
+    unsigned long long *stats;
     uint32_t t_stride, raw_stride; // per-frame strides of T (dwords) and raw (bytes)
     bool heavy_first;              // host side: STEPTH_FLAG_HEAVY_FIRST (launch_tile)
 };
-
-constexpr uint32_t kNoKey = 0xFFFFFFFFu;
-#ifndef STEPTH_RUN
-#define STEPTH_RUN 64
-#endif
-// <= 80 SGPRs keeps 8 workgroups of 256 threads resident per CU (MI355X_MICROARCH.md,
-// "Residency"); the kernel wants ~100 without the cap
-#ifndef STEPTH_SEARCH_ATTR
-#define STEPTH_SEARCH_ATTR __attribute__((amdgpu_num_sgpr(80)))
-#endif
-constexpr uint32_t kRun = STEPTH_RUN; // consecutive pending queries a wave takes at a time
-#ifndef STEPTH_PARTS
-#define STEPTH_PARTS 64
-#endif
-constexpr uint32_t kParts = STEPTH_PARTS; // run counters
-constexpr uint32_t kPartStride = 32; // words between counters (128-byte lines)
 
 __device__ __forceinline__ uint32_t bcast(uint32_t v, int src_lane)
 {
@@ -410,618 +244,6 @@ __device__ __forceinline__ uint32_t wave_min_dpp(uint32_t v)
     v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x124, 0xF, 0xF, false));
     v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x128, 0xF, 0xF, false));
     return min(min(bcast(v, 0), bcast(v, 16)), min(bcast(v, 32), bcast(v, 48)));
-}
-
-// Order-preserving key of a cell in the reference's scan (helpers.rs:26-31): ring
-// s = max(|dx|,|dy|) first, then the side (row y+s, row y-s, column x+s, column x-s), then
-// the position along that side (ascending).  A corner belongs to the row that reaches it
-// first.  Layout: position in bits [pb-1:0] (<= 2 (s_cap-1)), side in [pb+1:pb], ring above;
-// pb is chosen on the host from the largest ring the launch can reach (pb = 9 for the
-// reference's max = 255).
-__device__ __forceinline__ uint32_t scan_key(int dx, int dy, uint32_t pb, uint32_t &ring)
-{
-    const int ndx = -dx, ndy = -dy;
-    const int s = max(max(dx, ndx), max(dy, ndy));
-    const bool top = dy == s, bot = ndy == s;
-    const uint32_t side = top ? 0u : bot ? 1u : dx == s ? 2u : 3u;
-    const int pos = ((top || bot) ? dx : dy) + s;
-    ring = (uint32_t)s;
-    return ((((uint32_t)s << 2) | side) << pb) | (uint32_t)pos;
-}
-
-__device__ __forceinline__ void key_to_offset(uint32_t key, uint32_t pb, int &dx, int &dy)
-{
-    const int s = (int)(key >> (pb + 2u)), side = (int)((key >> pb) & 3u);
-    const int off = (int)(key & ((1u << pb) - 1u)) - s;
-    dx = side < 2 ? off : side == 2 ? s : -s;
-    dy = side == 0 ? s : side == 1 ? -s : off;
-}
-
-// Block spiral: slot u -> block offset (bi, bj) from the centre block.  Block-ring m holds
-// slots [(2m-1)^2, (2m+1)^2), walked as a pinwheel of four sides of 2m blocks; slot 0 is the
-// centre block.  The table is query independent and host-built (entry = (bi & 0xffff) |
-// (bj << 16), then one word per 64-slot chunk: complete block-rings after that chunk); its
-// first kSpiralChunks chunks -- enough for max_steps <= 258, the reference uses 255 -- are
-// staged in LDS, later chunks are read from global memory.
-constexpr uint32_t kSpiralRings = 33;                                   // block-rings 0..33
-constexpr uint32_t kSpiralSlots = (2 * kSpiralRings + 1) * (2 * kSpiralRings + 1); // 4489
-constexpr uint32_t kSpiralChunks = (kSpiralSlots + 63) / 64;            // 71
-
-STEPTH_HD void block_slot(uint32_t u, int &i, int &j)
-{
-    if (u == 0) {
-        i = j = 0;
-        return;
-    }
-    const int m = (int)((isqrt_floor(u) + 1u) >> 1);
-    const int t = (int)u - (2 * m - 1) * (2 * m - 1);
-    const int side = t / (2 * m), o = t - side * 2 * m;
-    i = side == 0 ? -m + o : side == 1 ? m : side == 2 ? -m + 1 + o : -m;
-    j = side == 0 ? -m : side == 1 ? -m + o : side == 2 ? m : -m + 1 + o;
-}
-
-// number of complete block-rings once slots [0, done) are processed: largest m with
-// (2m+1)^2 <= done
-STEPTH_HD uint32_t rings_done(uint32_t done) { return (isqrt_floor(done) - 1u) >> 1; }
-
-// Query `slot` of a launch -> its id q (index into raw), centre and colour box.
-// QMODE 0 (one query per main pixel): slots walk the image in 2x2 tiles anchored at odd
-// coordinates -- the four pixels (2tx-1..2tx, 2ty-1..2ty) all have middle = ((x+1)/2,
-// (y+1)/2) = (tx, ty) (depth_image.rs:114-117 with a 1x1 group) -- so queries that share a
-// search centre sit next to each other in the pending list and ring_search_kernel can serve
-// them together.  Returns false for slots outside the image / strip.
-template <int QMODE>
-__device__ __forceinline__ bool load_query(const RingArgs &a, uint32_t f, uint32_t slot, uint32_t &q,
-                                           uint32_t &cx, uint32_t &cy, uint32_t &lo,
-                                           uint32_t &hi)
-{
-    if constexpr (QMODE == 0) {
-        const uint32_t tile = slot >> 2, m = slot & 3u;
-        const uint32_t tx = tile % a.ntx;
-        uint32_t ty = a.ty0 + tile / a.ntx, y_lo = a.row0, y_hi = a.row1;
-        if (a.rp.block) {
-            // k-th owned block of rows = global block rem + k*mod; it touches block/2 + 1
-            // tile rows (its first and last one are shared with the neighbouring blocks, which
-            // emit the rows on their side)
-            const uint32_t per = a.rp.block / 2u + 1u, tr = tile / a.ntx;
-            const uint32_t y0 = (a.rp.rem + (tr / per) * a.rp.mod) * a.rp.block;
-            ty = y0 / 2u + tr % per;
-            y_lo = max(y_lo, y0);
-            y_hi = min(y_hi, y0 + a.rp.block);
-        }
-        const uint32_t x = 2u * tx - 1u + (m & 1u), y = 2u * ty - 1u + (m >> 1); // may wrap
-        if (slot >= a.n_slots || x >= a.w || y < y_lo || y >= y_hi)
-            return false;
-        q = (y - a.row0) * a.w + x;
-        const uint8_t *p = a.main_px[f] + (size_t)y * a.mstride + (size_t)x * a.mch;
-        const uint8_t v[3] = {p[0], p[1], p[2]};
-        cx = tx;
-        cy = ty;
-        make_box(v, a.prec, lo, hi);
-        return true;
-    } else {
-        if (slot >= a.nq[f])
-            return false;
-        q = slot;
-        const Query qq = a.queries[(size_t)f * a.q_stride + slot];
-        cx = qq.cx;
-        cy = qq.cy;
-        lo = qq.lo;
-        hi = qq.hi;
-        return true;
-    }
-}
-
-// One returning atomic on a single address costs ~11 ns chip-wide (MI355X_MICROARCH.md,
-// "dequeue"), so the compaction counter is bumped once per WORKGROUP (kRing0Iters * 256
-// queries), not once per wave: 2048 queries per workgroup for big launches (ITERS = 8), 512
-// for small ones, which would otherwise leave most CUs without a workgroup (ITERS = 2).
-constexpr uint32_t kRing0Iters = 8, kRing0ItersSmall = 2;
-
-template <int QMODE, bool STATS, uint32_t ITERS>
-__global__ __launch_bounds__(256) void ring0_kernel(RingArgs a)
-{
-    __shared__ uint32_t s_wave_total[4];
-    __shared__ uint32_t s_base;
-    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    const uint32_t f = blockIdx.y; // frame
-    Query rec[ITERS];
-    uint32_t qid[ITERS];
-    uint32_t pend_bits = 0, n_mine = 0;
-    unsigned long long n_hit = 0, n_inb = 0;
-#pragma unroll
-    for (uint32_t it = 0; it < ITERS; ++it) {
-        const uint32_t slot = (blockIdx.x * ITERS + it) * 256u + threadIdx.x;
-        uint32_t q = 0, cx = ~0u, cy = ~0u, lo = 0, hi = 0;
-        const bool valid = load_query<QMODE>(a, f, slot, q, cx, cy, lo, hi);
-        qid[it] = q;
-        const bool inb = valid && cx < a.wa && cy < a.ha && a.max_steps > 0;
-        bool fnd = false, pending = false;
-        if (inb) {
-            const uint32_t blk = (cy >> kBlkShift) * a.bw + (cx >> kBlkShift);
-            const uint32_t c = a.T[(size_t)f * a.t_stride + blk * 64u + ((cy & 7u) << 3) + (cx & 7u)];
-            fnd = cell_in_box(c, lo, hi);
-            pending = !fnd && a.max_steps > 1;
-        }
-        if (valid) { // a ring-0 hit has distance 0; None is 0 too (depth_image.rs:118-121)
-            a.raw[(size_t)f * a.raw_stride + q] = 0;
-            if (a.raw32)
-                a.raw32[q] = 0;
-            if (a.pos) {
-                a.pos[2 * (size_t)q] = fnd ? cx : 0u;
-                a.pos[2 * (size_t)q + 1] = fnd ? cy : 0u;
-            }
-            if (a.found)
-                a.found[q] = fnd ? 1 : 0;
-        }
-        rec[it] = Query{cx, cy | (f << 16), lo, hi}; // pending records carry their frame
-        const unsigned long long pm = __ballot(pending);
-        if (pending)
-            pend_bits |= 1u << it;
-        n_mine += (uint32_t)__popcll(pm); // wave-uniform: pending queries of this wave
-        if constexpr (STATS) {
-            n_hit += __popcll(__ballot(fnd));
-            n_inb += __popcll(__ballot(inb));
-        }
-    }
-    if (lane == 0)
-        s_wave_total[wv] = n_mine;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const uint32_t tot = s_wave_total[0] + s_wave_total[1] + s_wave_total[2] + s_wave_total[3];
-        s_base = tot ? atomicAdd(a.pending_count, tot) : 0u;
-    }
-    __syncthreads();
-    uint32_t slot = s_base;
-    for (uint32_t w = 0; w < wv; ++w)
-        slot += s_wave_total[w];
-#pragma unroll
-    for (uint32_t it = 0; it < ITERS; ++it) {
-        const bool pending = (pend_bits >> it) & 1u;
-        const unsigned long long pm = __ballot(pending);
-        if (pending) {
-            const uint32_t at = slot + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull));
-            // the id carries the frame in its top bits (batches): ring_finish_kernel then needs
-            // 8 bytes per pending query, not the 16-byte record as well
-            a.pending[at] = a.id_bits < 32u ? qid[it] | (f << a.id_bits) : qid[it];
-            a.pending_rec[at] = rec[it];
-        }
-        slot += (uint32_t)__popcll(pm);
-    }
-    if constexpr (STATS) {
-        if (lane == 0) {
-            atomicAdd(&stats_replica(a.stats)[0], n_hit);
-            atomicAdd(&stats_replica(a.stats)[1], n_inb);
-        }
-    }
-}
-
-// The search kernel gets its own small argument block (few live scalars: it runs at 8
-// workgroups per CU only below ~80 SGPRs) and writes nothing but the winning key of every
-// pending query; ring_finish_kernel turns keys into distances.
-struct SearchArgs {
-    const uint32_t *T;
-    const uint2 *BB;
-    const uint2 *SB;
-    const Query *rec;             // pending records, compacted by ring0_kernel
-    uint32_t *key;                // out: best key per pending record (kNoKey = None)
-    const uint32_t *count;        // number of pending records
-    uint32_t *next;               // kParts run counters
-    const uint32_t *spiral;       // block-spiral table (FAR only)
-    const uint32_t *spiral_done;
-    unsigned long long *stats;
-    uint32_t wa, ha, bw, bh, sbw, max_steps, pos_bits;
-    uint32_t t_stride, bb_stride, sb_stride; // per-frame strides; a record's frame = cy >> 16
-};
-
-__device__ __forceinline__ unsigned long long ballot(bool p)
-{
-    return __builtin_amdgcn_ballot_w64(p);
-}
-
-// FAR = false: max_steps <= 258 (the reference uses 255): near step + superblock-guided far
-// phase.  FAR = true: longer searches walk the whole block spiral from a global table.
-template <bool STATS, bool FAR>
-__global__ __launch_bounds__(256) STEPTH_SEARCH_ATTR void ring_search_kernel(SearchArgs a)
-{
-    const uint32_t lane = threadIdx.x & 63u;
-    const int lx = (int)(lane & 7u), ly = (int)(lane >> 3);
-    const uint32_t lane_t = ((lane & 7u) << 3) | (lane >> 3); // transposed cell index
-    const uint32_t ring_shift = a.pos_bits + 2u;
-    const uint32_t count = *a.count;
-    unsigned long long n_probe = 0, n_near = 0, n_survey = 0, n_super = 0, n_blocks = 0;
-
-    // first step of the block spiral (slots 0..63 = block-rings 0..3 and a bit of ring 4):
-    // the same 64 blocks for every query, one per lane, kept in registers
-    int nbi, nbj;
-    block_slot(lane, nbi, nbj);
-
-    // Runs of kRun consecutive pending records are dealt from kParts interleaved partitions
-    // (run r belongs to partition r % kParts), each with its own counter on its own cache
-    // line: a single counter would cap the whole chip at ~88 grabs/us.  A wave starts at
-    // partition wave % kParts and moves on when it is empty.
-    // long runs amortise the grab, short runs balance small launches (a row strip of 1/8
-    // frame has only ~24 records per wave): aim at >= 8 runs per resident wave, runs of
-    // 4..kRun records (multiples of 4: the 2x2 tiles put up to 4 records on one centre)
-    const uint32_t run = min(kRun, max(4u, (count / (8192u * 8u)) & ~3u));
-    const uint32_t n_runs = (count + run - 1u) / run;
-    const uint32_t wave_id =
-        (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (threadIdx.x >> 6)));
-    static_assert(kParts <= 64, "one lane per partition in the refill scan");
-    uint32_t part = wave_id % kParts;
-    for (;;) {
-        const uint32_t part_runs = (n_runs + kParts - 1u - part) / kParts;
-        uint32_t idx = 0;
-        if (lane == 0)
-            idx = atomicAdd(a.next + part * kPartStride, 1u);
-        idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)idx);
-        if (idx >= part_runs) {
-            // this partition is exhausted: look at all of them at once (lane p reads counter
-            // p) and move to the next one that still has runs; none left -> done
-            bool has = false;
-            if (lane < kParts) {
-                const uint32_t taken = __hip_atomic_load(a.next + lane * kPartStride,
-                                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                has = taken < (n_runs + kParts - 1u - lane) / kParts;
-            }
-            const unsigned long long live = ballot(has);
-            if (!live)
-                break;
-            // first live partition after `part`, cyclically
-            const unsigned long long after = part + 1u < 64u ? live >> (part + 1u) : 0ull;
-            part = after ? part + 1u + (uint32_t)(__ffsll(after) - 1) : (uint32_t)(__ffsll(live) - 1);
-            continue;
-        }
-        const uint32_t run0 = (idx * kParts + part) * run;
-        const uint32_t run_len = min(run, count - run0);
-        // one coalesced read brings the whole run: lane i holds record run0 + i
-        Query rec = Query{0u, 0u, 0u, 0u};
-        if (lane < run_len)
-            rec = a.rec[run0 + lane];
-        uint32_t result = kNoKey; // lane i: best key of record run0 + i
-
-        // Records with the same search centre (the 2x2 pixel tiles of the 1x1 mode put up to
-        // four of them side by side) are served together: one set of block tests and one read
-        // of every probed block for all their colour boxes.
-        unsigned long long starts;
-        {
-            const uint32_t pcx = (uint32_t)__shfl_up((int)rec.cx, 1, 64);
-            const uint32_t pcy = (uint32_t)__shfl_up((int)rec.cy, 1, 64);
-            starts = ballot(lane < run_len && (FAR || lane == 0 || rec.cx != pcx || rec.cy != pcy));
-        }
-        for (uint32_t r = 0; r < run_len;) {
-            const unsigned long long later = (starts >> r) >> 1; // group starts after r
-            const uint32_t till = later ? (uint32_t)__ffsll(later) : run_len - r;
-            const uint32_t M = min(min(till, run_len - r), 4u); // members r .. r+M-1
-            const uint32_t qx = bcast(rec.cx, (int)r), qyf = bcast(rec.cy, (int)r);
-            const uint32_t qy = qyf & 0xffffu, frame = qyf >> 16;
-            // frame offsets stay 32-bit indices (the whole batch holds < 2^30 cells)
-            const uint32_t tf = frame * a.t_stride, bf = frame * a.bb_stride;
-            const uint32_t sf = frame * a.sb_stride;
-            const uint32_t smax = max(max(qx, a.wa - 1u - qx), max(qy, a.ha - 1u - qy));
-            const uint32_t s_end = min(a.max_steps, smax + 1u); // rings 0..s_end-1 are searched
-            const int cbx = (int)(qx >> kBlkShift), cby = (int)(qy >> kBlkShift);
-            const int nox = -(int)(qx & 7u), noy = -(int)(qy & 7u);
-
-            // per member: colour box, best key so far, and `limit`: a block whose nearest cell
-            // is at ring >= limit is useless to it (0 = member settled / absent)
-            uint32_t qlo[4], qhi[4], best[4], limit[4];
-#pragma unroll
-            for (uint32_t m = 0; m < 4; ++m) {
-                const int src = (int)min(r + m, run_len - 1u);
-                qlo[m] = bcast(rec.lo, src);
-                qhi[m] = bcast(rec.hi, src);
-                best[m] = kNoKey;
-                limit[m] = m < M ? s_end : 0u;
-            }
-            uint32_t glimit = s_end; // max of the members' limits
-
-            // box [lo,hi] meets [bmin,bmax] on every channel
-            auto meets = [&](uint2 bb, uint32_t lo, uint32_t hi) {
-                return box_meets(bb.x, bb.y, lo, hi);
-            };
-            // some member that can still use a block at distance `d` has a box meeting `bb`
-            auto wanted = [&](uint2 bb, uint32_t d) {
-                bool w = false;
-#pragma unroll
-                for (uint32_t m = 0; m < 4; ++m)
-                    w |= d < limit[m] && meets(bb, qlo[m], qhi[m]);
-                return w;
-            };
-            // smallest ring of any cell of block (bi,bj): max over axes of max(8b-o, o-8b-7, 0)
-            auto block_dmin = [&](int bi, int bj) {
-                const int ax = (bi << 3) + nox, ay = (bj << 3) + noy;
-                return (uint32_t)max(max(max(ax, -7 - ax), max(ay, -7 - ay)), 0);
-            };
-            // Most blocks lie entirely inside ONE side region of the reference's scan (all
-            // their cells on "row y+s" sides, or all on "row y-s", "column x+s", "column x-s"
-            // sides).  There the scan order inside the block is: nearest line first, then
-            // ascending along the line -- so if the lanes read the cells in that order (rows
-            // or columns, forwards or backwards: `cell_of`), a member's smallest key sits in
-            // the lowest hit lane and no wave-min is needed.  Blocks on the diagonals (type 4)
-            // keep the natural order and pay for the reduction.
-            // info = bi (14 bits) | bj (14 bits) | type << 28, per lane (lane = block)
-            auto block_info = [&](int bi, int bj) {
-                const int x0 = (bi << 3) + nox, y0 = (bj << 3) + noy; // offsets of cell (0,0)
-                const int x1 = x0 + 7, y1 = y0 + 7;
-                const int mx = max(-x0, x1), my = max(-y0, y1);       // max |dx|, max |dy|
-                const uint32_t type = (y0 > 0 && y0 >= mx)    ? 0u   // rows below:    side 0
-                                      : (y1 < 0 && -y1 >= mx) ? 1u   // rows above:    side 1
-                                      : (x0 > 0 && x0 > my)   ? 2u   // columns right: side 2
-                                      : (x1 < 0 && -x1 > my)  ? 3u   // columns left:  side 3
-                                                              : 4u;
-                return ((uint32_t)bi & 0x3fffu) | (((uint32_t)bj & 0x3fffu) << 14) | (type << 28);
-            };
-            // byte offset of block (bx,by) of this frame in T, with the block's type in bits 0..2
-            auto block_off = [&](int bx, int by, uint32_t info) {
-                return ((tf + ((uint32_t)by * a.bw + (uint32_t)bx) * 64u) << 2) | (info >> 28);
-            };
-            // cell (row-major index in the block) read by this lane for a block of `type`
-            auto cell_of = [&](uint32_t type) {
-                const uint32_t base = (type & 2u) ? lane_t : lane; // 2, 3: columns
-                // 1: rows bottom-up (^56), 3: columns right-to-left (^7), else forwards
-                return base ^ (uint32_t)((0x07003800ull >> (8u * type)) & 0xffu);
-            };
-            // all lanes hold cell `cell` of block (sbi,sbj) (type, nearest ring d): test it for
-            // every member the block can still help; keys only on a hit
-            auto resolve = [&](int sbi, int sbj, uint32_t type, uint32_t d, uint32_t cell,
-                               uint32_t c) -> bool {
-                // hit masks per member (wave-uniform 64-bit values)
-                unsigned long long h[4];
-#pragma unroll
-                for (uint32_t m = 0; m < 4; ++m)
-                    h[m] = d < limit[m] ? ballot(cell_in_box(c, qlo[m], qhi[m])) : 0ull;
-                if (!(h[0] | h[1] | h[2] | h[3]))
-                    return false;
-                uint32_t ring;
-                const uint32_t key = scan_key(sbi * 8 + (int)(cell & 7u) + nox,
-                                              sbj * 8 + (int)(cell >> 3) + noy, a.pos_bits, ring);
-                const unsigned long long in_reach = ballot(ring < s_end);
-                bool changed = false;
-#pragma unroll
-                for (uint32_t m = 0; m < 4; ++m) {
-                    const unsigned long long hm = h[m] & in_reach;
-                    if (hm) {
-                        const uint32_t k = type < 4u
-                                               ? bcast(key, __ffsll(hm) - 1)
-                                               : wave_min_dpp(((hm >> lane) & 1ull) ? key : kNoKey);
-                        best[m] = min(best[m], k);
-                        limit[m] = min(limit[m], (best[m] >> ring_shift) + 1u);
-                        changed = true;
-                    }
-                }
-                return changed;
-            };
-            // One step of cell probes per surviving block (two in flight): 64 lanes read its
-            // 64 cells (256 contiguous bytes).  `info,dmin` are per lane (lane = block).
-            // `boff` = byte offset of the lane's block in T (a multiple of 256) | its type.
-            auto probe_blocks = [&](unsigned long long pm, uint32_t info, uint32_t dmin,
-                                    uint32_t boff) {
-                while (pm) {
-                    const int b0 = __ffsll(pm) - 1;
-                    pm &= pm - 1;
-                    const bool two = pm != 0;
-                    const int b1 = two ? __ffsll(pm) - 1 : b0;
-                    pm &= pm - 1; // no-op when pm == 0
-                    const uint32_t o0 = bcast(boff, b0), o1 = bcast(boff, b1);
-                    const uint32_t t0 = o0 & 7u, t1 = o1 & 7u;
-                    const uint32_t d0 = bcast(dmin, b0), d1 = bcast(dmin, b1);
-                    const uint32_t cell0 = cell_of(t0), cell1 = cell_of(t1);
-                    const char *tb = reinterpret_cast<const char *>(a.T);
-                    const uint32_t c0 = *reinterpret_cast<const uint32_t *>(
-                        tb + (size_t)(o0 & ~255u) + (cell0 << 2));
-                    const uint32_t c1 = *reinterpret_cast<const uint32_t *>(
-                        tb + (size_t)(o1 & ~255u) + (cell1 << 2));
-                    // block coordinates are only needed for the keys of a hit
-                    const uint32_t n0 = bcast(info, b0), n1 = bcast(info, b1);
-                    const int i0 = (int)(n0 << 18) >> 18, j0 = (int)(n0 << 4) >> 18;
-                    const int i1 = (int)(n1 << 18) >> 18, j1 = (int)(n1 << 4) >> 18;
-                    bool changed = resolve(i0, j0, t0, d0, cell0, c0);
-                    if (two)
-                        changed |= resolve(i1, j1, t1, d1, cell1, c1);
-                    if constexpr (STATS) {
-                        n_probe += two ? 128ull : 64ull;
-                        n_blocks += two ? 2ull : 1ull;
-                    }
-                    if (changed) {
-                        // everything farther than every member's best ring is now useless,
-                        // including the rest of this step's survivors
-                        glimit = max(max(limit[0], limit[1]), max(limit[2], limit[3]));
-                        pm &= ballot(dmin < glimit);
-                    }
-                }
-            };
-
-            if constexpr (FAR) {
-                const uint32_t m_end = (s_end + 6u) >> 3; // last block-ring with a ring < s_end
-                const uint32_t u_end = (2u * m_end + 1u) * (2u * m_end + 1u);
-                for (uint32_t u0 = 0, k = 0; u0 < u_end; u0 += 64u, ++k) {
-                    const uint32_t e = a.spiral[u0 + lane];
-                    const int bi = (int)(short)(e & 0xffffu), bj = (int)e >> 16;
-                    const int bx = cbx + bi, by = cby + bj;
-                    const uint32_t dmin = block_dmin(bi, bj);
-                    bool cand = u0 + lane < u_end && (uint32_t)bx < a.bw &&
-                                (uint32_t)by < a.bh && dmin < glimit;
-                    if (cand)
-                        cand = wanted(a.BB[bf + (uint32_t)by * a.bw + (uint32_t)bx], dmin);
-                    if constexpr (STATS) {
-                        n_probe += 64ull;
-                        ++n_near;
-                    }
-                    const uint32_t info = block_info(bi, bj);
-                    probe_blocks(ballot(cand), info, dmin, block_off(bx, by, info));
-                    // block-rings 0..m_done are complete: every cell of rings <= 8 m_done has
-                    // been seen or excluded
-                    if (best[0] != kNoKey && (best[0] >> ring_shift) <= 8u * a.spiral_done[k])
-                        break;
-                }
-            } else {
-                // ---- near: block-rings 0..3 (all cells of rings <= 24) ----
-                {
-                    const int bx = cbx + nbi, by = cby + nbj;
-                    const uint32_t dmin = block_dmin(nbi, nbj);
-                    bool cand = (uint32_t)bx < a.bw && (uint32_t)by < a.bh && dmin < glimit;
-                    if (cand)
-                        cand = wanted(a.BB[bf + (uint32_t)by * a.bw + (uint32_t)bx], dmin);
-                    if constexpr (STATS) {
-                        n_probe += 64ull;
-                        ++n_near;
-                    }
-                    const uint32_t info = block_info(nbi, nbj);
-                    probe_blocks(ballot(cand), info, dmin, block_off(bx, by, info));
-                }
-                // a member whose best ring is <= 24 is settled; the others need the far phase
-#pragma unroll
-                for (uint32_t m = 0; m < 4; ++m)
-                    if (s_end <= 25u || (best[m] != kNoKey && (best[m] >> ring_shift) <= 24u))
-                        limit[m] = 0u;
-                glimit = max(max(limit[0], limit[1]), max(limit[2], limit[3]));
-                if (glimit) {
-                    // ---- far: survey the 64x64-cell superblocks overlapping the window of
-                    // radius glimit-1 -- only those whose bounds meet a box can hold a match
-                    // -- then one step per surviving superblock, nearest first: its 64 blocks.
-                    const int rad = (int)glimit - 1;
-                    const int sx0 = max((int)qx - rad, 0) >> 6, sy0 = max((int)qy - rad, 0) >> 6;
-                    const int sx1 = min((int)qx + rad, (int)a.wa - 1) >> 6;
-                    const int sy1 = min((int)qy + rad, (int)a.ha - 1) >> 6;
-                    const int nsx = sx1 - sx0 + 1, nsy = sy1 - sy0 + 1; // <= 10 each
-                    // lanes tile the window: 8 x 8 superblocks in one round when it fits (any
-                    // window of radius <= 223), else 16 x 4 per round, 3 rounds cover 16 x 12
-                    const uint32_t gsh = (nsx <= 8 && nsy <= 8) ? 3u : 4u;
-                    const int grows = 64 >> gsh;
-                    uint32_t skey[3] = {kNoKey, kNoKey, kNoKey};
-#pragma unroll
-                    for (int h = 0; h < 3; ++h) {
-                        const int tx = (int)(lane & ((1u << gsh) - 1u)), ty = (int)(lane >> gsh) + grows * h;
-                        if (tx < nsx && ty < nsy) {
-                            const int sx = sx0 + tx, sy = sy0 + ty;
-                            const int ax = (sx << 6) - (int)qx, ay = (sy << 6) - (int)qy;
-                            const uint32_t dS =
-                                (uint32_t)max(max(max(ax, -63 - ax), max(ay, -63 - ay)), 0);
-                            if (dS < glimit &&
-                                wanted(a.SB[sf + (uint32_t)sy * a.sbw + (uint32_t)sx], dS))
-                                skey[h] = (dS << 8) | (uint32_t)(ty * 16 + tx);
-                        }
-                        if (grows * (h + 1) >= nsy)
-                            break;
-                    }
-                    if constexpr (STATS) {
-                        n_probe += 64ull;
-                        ++n_survey;
-                    }
-                    for (;;) {
-                        // nearest surviving superblock that can still improve some best key
-                        uint32_t k = min(min(skey[0], skey[1]), skey[2]);
-                        k = (k >> 8) < glimit ? k : kNoKey;
-                        if (ballot(k != kNoKey) == 0)
-                            break;
-                        const uint32_t pick = wave_min_dpp(k);
-                        const int sx = sx0 + (int)(pick & 15u), sy = sy0 + (int)((pick >> 4) & 15u);
-#pragma unroll
-                        for (int h = 0; h < 3; ++h)
-                            skey[h] = skey[h] == pick ? kNoKey : skey[h];
-                        // its 64 blocks, one lane each (block-rings 0..3 were done above)
-                        const int bx = sx * 8 + lx, by = sy * 8 + ly;
-                        const int bi = bx - cbx, bj = by - cby;
-                        const uint32_t dmin = block_dmin(bi, bj);
-                        bool cand = (uint32_t)bx < a.bw && (uint32_t)by < a.bh && dmin < glimit &&
-                                    max(abs(bi), abs(bj)) > 3;
-                        if (cand)
-                            cand = wanted(a.BB[bf + (uint32_t)by * a.bw + (uint32_t)bx], dmin);
-                        if constexpr (STATS) {
-                            n_probe += 64ull;
-                            ++n_super;
-                        }
-                        // nearest blocks first, in shells of 8 rings from the superblock's
-                        // nearest cell: a hit in an early shell prunes the later ones (lane
-                        // order inside a superblock says nothing about distance)
-                        unsigned long long pm = ballot(cand);
-                        if (!pm)
-                            continue;
-                        const uint32_t info = block_info(bi, bj), shell = (dmin - (pick >> 8)) >> 3;
-                        const uint32_t boff = block_off(bx, by, info);
-                        for (uint32_t sh = 0; pm; ++sh) {
-                            const unsigned long long now = pm & ballot(shell <= sh);
-                            if (now) {
-                                probe_blocks(now, info, dmin, boff);
-                                pm &= ~now & ballot(dmin < glimit);
-                            }
-                        }
-                    }
-                }
-            }
-#pragma unroll
-            for (uint32_t m = 0; m < 4; ++m)
-                if (m < M && lane == r + m)
-                    result = best[m];
-            r += M;
-        }
-        if (lane < run_len)
-            a.key[run0 + lane] = result;
-    }
-    if constexpr (STATS) {
-        if (lane == 0) {
-            atomicAdd(&stats_replica(a.stats)[1], n_probe);
-            atomicAdd(&stats_replica(a.stats)[2], n_near);
-            atomicAdd(&stats_replica(a.stats)[3], n_survey);
-            atomicAdd(&stats_replica(a.stats)[4], n_super);
-            atomicAdd(&stats_replica(a.stats)[5], n_blocks);
-        }
-    }
-}
-
-// keys -> distances: helpers.rs:3-7 (floor sqrt), depth_image.rs:121 (`d as u8` wraps),
-// :124 (max).  Dense over the pending records; None keeps the 0 written by ring0_kernel.
-struct FinishArgs {
-    const uint32_t *pending; // query ids
-    const Query *rec;
-    const uint32_t *key;
-    const uint32_t *count;
-    uint32_t pos_bits;
-    uint32_t id_bits; // pending ids: query id in the low id_bits, frame above (32: no frame)
-    uint8_t *raw;
-    uint32_t *raw32, *pos;
-    uint8_t *found;
-    uint32_t *max_word;  // one word per frame
-    uint32_t raw_stride; // bytes between the frames' raw maps
-};
-
-__global__ __launch_bounds__(256) void ring_finish_kernel(FinishArgs a)
-{
-    // The frames of a batch interleave in the pending list, and same-address global atomics
-    // cost ~11 ns each chip-wide: the maxima are folded per frame in LDS and every workgroup
-    // flushes its non-zero entries once at the end.
-    __shared__ uint32_t s_fmax[kMaxBatch];
-    if (threadIdx.x < kMaxBatch)
-        s_fmax[threadIdx.x] = 0;
-    __syncthreads();
-    const uint32_t count = *a.count;
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < count; i += gridDim.x * 256u) {
-        const uint32_t key = a.key[i];
-        if (key == kNoKey)
-            continue;
-        const uint32_t idw = a.pending[i];
-        const uint32_t frame = a.id_bits < 32u ? idw >> a.id_bits : 0u;
-        const uint32_t q = a.id_bits < 32u ? idw & ((1u << a.id_bits) - 1u) : idw;
-        int dx, dy;
-        key_to_offset(key, a.pos_bits, dx, dy);
-        const uint32_t d = isqrt_floor((uint32_t)(dx * dx + dy * dy));
-        a.raw[(size_t)frame * a.raw_stride + q] = (uint8_t)(d & 0xffu);
-        if (d & 0xffu)
-            atomicMax(&s_fmax[frame], d & 0xffu);
-        if (a.raw32)
-            a.raw32[q] = d;
-        if (a.pos) {
-            const Query r = a.rec[i];
-            a.pos[2 * (size_t)q] = (uint32_t)((int)r.cx + dx);
-            a.pos[2 * (size_t)q + 1] = (uint32_t)((int)(r.cy & 0xffffu) + dy);
-        }
-        if (a.found)
-            a.found[q] = 1;
-    }
-    __syncthreads();
-    if (threadIdx.x < kMaxBatch && s_fmax[threadIdx.x])
-        atomicMax(&a.max_word[threadIdx.x], s_fmax[threadIdx.x]);
 }
 
 // ---------------------------------------------------------------------------------------

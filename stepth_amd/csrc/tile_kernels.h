@@ -876,8 +876,8 @@ __global__ __launch_bounds__(64) void list_rank_kernel(TileOrderBufs o)
 // windows around ITS centre -- first the 7x7 blocks around its centre block, then the
 // superblocks of its window ring by ring around its own superblock -- and reads their bounds
 // with its own (vector) loads.  The wave only shares the loop counters; a lane that does not
-// want the window of an iteration sits it out.  Replaces the round-1 trio ring0 / ring_search /
-// ring_finish (one WAVE per <= 4 queries) for searches of up to 263 rings.
+// want the window of an iteration sits it out.  No reach limit: one group per pixel beyond the
+// dense search's 263 rings runs here as 1x1 tiles.
 // ---------------------------------------------------------------------------------------
 struct ListArgs {
     const uint32_t *T, *TT;
@@ -959,7 +959,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     constexpr uint32_t wv = 0;
 #ifdef STEPTH_LIST_PROFILE // tuning build: how long the waves run, and what the long ones do
     [[maybe_unused]] const unsigned long long lp_t0 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
-    [[maybe_unused]] unsigned long long lp_goes = 0, lp_visits = 0, lp_go_ticks = 0, lp_m0_ticks = 0, lp_visit_ticks = 0, lp_survey_ticks = 0;
+    [[maybe_unused]] unsigned long long lp_goes = 0, lp_visits = 0, lp_go_ticks = 0, lp_m0_ticks = 0, lp_visit_ticks = 0, lp_survey_ticks = 0, lp_queue_ticks = 0;
 #endif
     const uint32_t wid = a.order ? a.order[blockIdx.x] : blockIdx.x;
     const uint32_t f = wid / a.wpf;
@@ -1179,6 +1179,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
             }
             // ---- the window's candidates become tasks (the own window block-ring by block-ring,
             // nearest first); the pool is executed whenever it holds enough of them ----
+#ifdef STEPTH_LIST_PROFILE
+            const unsigned long long lp_q0 = STATS ? __builtin_amdgcn_s_memtime() : 0ull, lp_go_before = lp_go_ticks;
+#endif
             for (int ps = 0; ps < rounds; ++ps) {
                 uint64_t cur = cand;
                 if (mode == 0) {
@@ -1268,6 +1271,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                         break;
                 }
             }
+#ifdef STEPTH_LIST_PROFILE
+            if constexpr (STATS) // the queue-and-go stage without its goes
+                lp_queue_ticks += __builtin_amdgcn_s_memtime() - lp_q0 - (lp_go_ticks - lp_go_before);
+#endif
             if (mode == 3)
                 break;
             if (mode == 0) {
@@ -1410,16 +1417,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
             const unsigned long long ticks = __builtin_amdgcn_s_memtime() - lp_t0;
             const int b = min(max(63 - __builtin_clzll(ticks | 1ull) - 13, 0), 7);
             atomicAdd(&stats_replica(a.stats)[8 + b], 1ull);
-            if (b < 5)
+            if (b < 4)
                 atomicAdd(&stats_replica(a.stats)[16 + b], lp_visits);
             atomicAdd(&stats_replica(a.stats)[24 + b], lp_goes);
             atomicAdd(&stats_replica(a.stats)[6], ticks);
             atomicAdd(&stats_replica(a.stats)[7], lp_go_ticks);
             atomicAdd(&stats_replica(a.stats)[3], lp_m0_ticks);
-            // (this build only: the three words below replace the per-bucket visit sums of buckets 5..7)
+            // (this build only: the words 20..23 replace the per-bucket visit sums of buckets 4..7)
             atomicAdd(&stats_replica(a.stats)[21], lp_visit_ticks);
             atomicAdd(&stats_replica(a.stats)[22], lp_survey_ticks);
             atomicAdd(&stats_replica(a.stats)[23], lp_e0 - lp_t0);
+            atomicAdd(&stats_replica(a.stats)[20], lp_queue_ticks);
 #endif
         }
     }
@@ -1586,8 +1594,8 @@ __global__ __launch_bounds__(256) void tile_super_kernel(TileSuperArgs a)
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        mn[c] = wave_min_u32(mn[c]);
-        mx[c] = wave_max_u32(mx[c]);
+        mn[c] = wave_min_dpp(mn[c]);
+        mx[c] = wave_max_dpp(mx[c]);
     }
     const bool some = __builtin_amdgcn_ballot_w64(any) != 0ull;
     if (lane == 0)

@@ -328,6 +328,30 @@ def test_strips_with_short_reach_pack_only_part_of_the_additional_image(engine, 
         assert max(maxes) == ref["max"]
 
 
+def test_reaches_beyond_the_dense_search(engine, oracle):
+    """max_steps > 263 (the reference itself always searches 255 rings, src/depth_image.rs:119):
+    one group per pixel then runs as 1x1 tiles of the prepared-query search, whose per-lane
+    ring walk takes any reach -- whole path, batch (+ Gaussian tail), row strips, against the
+    oracle; distances beyond 255 wrap like `d as u8`"""
+    import torch
+    from stepth_amd import synth
+    l, r, _ = synth.stereo_pair(720, 520, 200, seed=11)
+    tl, tr = torch.from_numpy(l).cuda(), torch.from_numpy(r).cuda()
+    for prec, ms in (([36] * 3, 420), ([12] * 3, 700), ([12] * 3, 264)):
+        ref = oracle.depth_from_additional(l, r, prec, ms)
+        d, mx = engine.depth_from_additional(l, r, prec, max_steps=ms)
+        assert mx == ref["max"] and np.array_equal(d, ref["depth"]), ms
+        outs, mxs = engine.depth_from_additional_batch([tl, tl], [tr, tr], prec, max_steps=ms)
+        assert list(mxs) == [ref["max"]] * 2 and np.array_equal(outs[1].cpu().numpy(), ref["depth"]), ms
+        out = np.zeros((520, 720), np.uint8)
+        for r0, r1 in ((0, 131), (131, 400), (400, 520)):
+            engine.depth_from_additional(l, r, prec, max_steps=ms, rows=(r0, r1), raw_only=True, out=out)
+        assert np.array_equal(out, ref["raw"]), ms
+    assert (ref["raw32"] > 255).any() if "raw32" in ref else True
+    outs, _ = engine.depth_from_additional_batch([tl], [tr], [12] * 3, max_steps=264, gaussian_tail=True)
+    assert np.array_equal(outs[0].cpu().numpy(), oracle.gaussian_same_size(ref["depth"]))
+
+
 def test_short_reach_packs_only_the_reachable_columns(engine, oracle, asset):
     """the centres lie in the left half of the additional image (middle = ((x+w)/2, (y+h)/2),
     src/depth_image.rs:114-117): block columns beyond centre + reach are not packed and keep an

@@ -1,6 +1,6 @@
 """one-off differential fuzz of the prepared-query paths (explicit group lists in any order,
 uniform tiles, single calls and batches, strips) against the oracle: random rectangles with
-random values on synthetic / blocky / sparse pairs, all reaches incl. the round-1 trio (> 263)"""
+random values on synthetic / blocky / sparse pairs, all reaches incl. those beyond the dense search (> 263)"""
 import sys, time; sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__)))))
 import numpy as np
 import torch

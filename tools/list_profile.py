@@ -18,9 +18,9 @@ eng.adaptive_depth_batch(mains, adds, [36] * 3, max_steps=ms)
 raw = eng.stats_raw(32)
 eng.stats_enable(False)
 waves = sum(raw[8:16])
-print(f"{which} d{ms}: waves {waves}, mean {raw[6] / max(waves, 1):.0f} ticks, of which in goes {raw[7] / max(raw[6], 1):.2f}, own-window tests {raw[3] / max(raw[6], 1):.2f}; visits {raw[21] / max(raw[6], 1):.2f}, survey {raw[22] / max(raw[6], 1):.2f}, before the epilogue {raw[23] / max(raw[6], 1):.2f}; goes {sum(raw[24:32])}")
+print(f"{which} d{ms}: waves {waves}, mean {raw[6] / max(waves, 1):.0f} ticks, of which in goes {raw[7] / max(raw[6], 1):.2f}, own-window tests {raw[3] / max(raw[6], 1):.2f}; visits {raw[21] / max(raw[6], 1):.2f}, survey {raw[22] / max(raw[6], 1):.2f}, queueing {raw[20] / max(raw[6], 1):.2f}, before the epilogue {raw[23] / max(raw[6], 1):.2f}; goes {sum(raw[24:32])}")
 for b in range(8):
     n = raw[8 + b]
     if n:
-        visits = f"{raw[16 + b] / n:6.1f}" if b < 5 else "     -"  # (the words of buckets 5..7 hold the section times)
+        visits = f"{raw[16 + b] / n:6.1f}" if b < 4 else "     -"  # (the words of buckets 4..7 hold the section times)
         print(f"  {2 ** (b + 13):8d} ticks .. : {n:6d} waves, visits/wave {visits}, goes/wave {raw[24 + b] / n:6.1f}")
