@@ -58,7 +58,7 @@ struct stepth_engine {
     DevBuf stage_main, stage_add, stage_out, stage_groups;
     DevBuf queries_sorted, query_ids, query_bins; // group lists sorted by search-centre bin
     DevBuf queries, raw, aux32, aux_pos, aux_found, pending;
-    DevBuf sad_left, sad_right, gauss_tmp, gauss_io;
+    DevBuf gauss_tmp, gauss_io;
     DevBuf zone_counts, zone_tables; // depth_split: 256 counts and one ZoneTable per frame
     DevBuf group_out, group_list[3], group_counters; // adaptive grouping (group_entries.h)
     // host-image batches: two slots of device staging, copy streams and events (batch_host)
@@ -676,7 +676,7 @@ void stepth_engine_destroy(stepth_engine *e)
     (void)hipStreamSynchronize(e->stream);
     for (DevBuf *b : {&e->T, &e->TT, &e->LB, &e->BBp, &e->SBp, &e->stage_main, &e->stage_add, &e->stage_out,
                       &e->stage_groups, &e->queries, &e->queries_sorted, &e->query_ids, &e->query_bins, &e->raw, &e->aux32, &e->aux_pos,
-                      &e->aux_found, &e->pending, &e->sad_left, &e->sad_right, &e->gauss_tmp, &e->gauss_io,
+                      &e->aux_found, &e->pending, &e->gauss_tmp, &e->gauss_io,
                       &e->zone_counts, &e->zone_tables, &e->pipe_main[0], &e->pipe_main[1],
                       &e->pipe_add[0], &e->pipe_add[1], &e->pipe_out[0], &e->pipe_out[1], &e->pipe_max, &e->group_out,
                       &e->group_list[0], &e->group_list[1], &e->group_list[2], &e->group_counters, &e->order_bytes, &e->order_words})
@@ -830,18 +830,6 @@ static int single_sad(stepth_engine *e, SingleCall &c, const stepth_group *group
         sa.thr = p.win * p.win * ((uint32_t)p.precision[0] + p.precision[1] + p.precision[2]);
         sa.raw = static_cast<uint8_t *>(e->raw.p);
         sa.max_word = e->words;
-        if (sad_has_fast_path(sa.win)) {
-            uint32_t prow = 0;
-            int apron = 0;
-            sad_plane_dims(sa, false, sa.lpitch, prow, apron);
-            TRY(reserve(e, e->sad_left, (size_t)sa.lpitch * prow * 4));
-            sad_plane_dims(sa, true, sa.rpitch, prow, apron);
-            TRY(reserve(e, e->sad_right, (size_t)sa.rpitch * prow * 4));
-            sa.lp = (uint32_t *)e->sad_left.p;
-            sa.rp = (uint32_t *)e->sad_right.p;
-            if (launch_sad_pack(sa, e->stream) != STEPTH_OK)
-                return fail(e, STEPTH_ERR_HIP, "sad_pack launch failed");
-        }
         {
             KernelTimer t(e);
             int s = launch_sad(sa, e->stream);
@@ -1165,20 +1153,6 @@ static int batch_sad(stepth_engine *e, uint32_t n_frames, const stepth_image *ma
         TRY(reserve(e, e->raw, sa.raw_stride * nf));
         sa.raw = static_cast<uint8_t *>(e->raw.p);
         sa.max_word = e->words;
-        if (sad_has_fast_path(sa.win)) {
-            uint32_t prow = 0;
-            int apron = 0;
-            sad_plane_dims(sa, false, sa.lpitch, prow, apron);
-            sa.lplane_stride = (size_t)sa.lpitch * prow;
-            TRY(reserve(e, e->sad_left, sa.lplane_stride * nf * 4));
-            sad_plane_dims(sa, true, sa.rpitch, prow, apron);
-            sa.rplane_stride = (size_t)sa.rpitch * prow;
-            TRY(reserve(e, e->sad_right, sa.rplane_stride * nf * 4));
-            sa.lp = (uint32_t *)e->sad_left.p;
-            sa.rp = (uint32_t *)e->sad_right.p;
-            if (launch_sad_pack(sa, e->stream) != STEPTH_OK)
-                return fail(e, STEPTH_ERR_HIP, "sad_pack launch failed");
-        }
         {
             KernelTimer t(e);
             const int s = launch_sad(sa, e->stream);

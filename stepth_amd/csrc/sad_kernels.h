@@ -6,14 +6,13 @@
 //   cost(x,y,d) = sum_{win x win} sum_c |L(x+i,y+j)_c - R(x+i-d,y+j)_c|   (clamp-to-edge)
 //   raw(x,y)    = smallest d in [0,d_max) with cost < win^2 (p0+p1+p2), else first argmin.
 //
-// Layout: both images are first packed into RGBX dword planes with an apron that bakes the
-// clamp-to-edge rule in (left apron rad [+ d_max-1 for R], right apron rad + 64, rad rows
-// above and below), so the search kernel never clamps an index.
-//
 // sad_search_kernel<WIN, DC, ROWS>: one wave = 64 adjacent columns x ROWS output rows.  Lane x
-// owns column x.  For a chunk of DC disparities it walks down the input rows; per row it
-// reads the WIN left cells and the DC+WIN-1 right cells its column needs (consecutive lanes
-// read consecutive dwords), forms the horizontal window sums H(d) with WIN chained v_sad_u8
+// owns column x.  For a chunk of DC disparities it walks down the input rows.  A row's pixels --
+// 64 + WIN-1 of the left image, 64 + DC+WIN-2 of the right one, clamp-to-edge applied to the
+// column and row indices -- are fetched from the RGB(A) images ONCE per wave, one row ahead of
+// the arithmetic, and handed to the lanes as RGBX dwords through LDS (until round 3 both images
+// were first packed into RGBX planes with aprons, 16 % of a call, and every lane loaded its 25
+// dwords itself).  Per row a lane forms the horizontal window sums H(d) with WIN chained v_sad_u8
 // per disparity -- neighbouring disparities reuse the same registers shifted by one -- and
 // keeps the vertical window as cost(d) += H_new(d) - H_old(d) with the last WIN rows of H in
 // a register ring (the row loop is unrolled WIN times so the ring is indexed statically).
@@ -35,15 +34,11 @@ struct SadArgs {
     size_t rstride;
     uint32_t n_frames;
     size_t raw_stride;                // bytes between the frames' raw maps
-    size_t lplane_stride, rplane_stride; // dwords between the frames' packed planes
     uint32_t w, h;
     uint32_t row0, row1;
     uint32_t d_max, win, thr;
     uint8_t *raw; // [frame][(row1-row0)][w]
     uint32_t *max_word; // one word per frame
-    // packed planes (sad_pack_kernel)
-    uint32_t *lp, *rp;
-    uint32_t lpitch, rpitch; // dwords
     uint32_t cols, strips;   // sad_search_kernel: waves per strip, strips per frame (launch_sad)
 };
 
@@ -56,31 +51,6 @@ __device__ __forceinline__ uint32_t load_rgbx(const uint8_t *img, size_t stride,
     return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
 }
 
-// plane[yy][xx] = RGBX(img[clamp(yy - rad)][clamp(xx - apron_l)])
-struct SadPackArgs {
-    const uint8_t *img[kMaxBatch]; // blockIdx.y = frame
-    size_t plane_stride;           // dwords between the frames' planes
-    size_t stride;
-    uint32_t ch, w, h;
-    int rad, apron_l, row0; // plane row r holds image row row0 - rad + r (clamped)
-    uint32_t pitch, rows;
-    uint32_t *plane;
-};
-
-__global__ __launch_bounds__(256) void sad_pack_kernel(SadPackArgs a)
-{
-    const size_t total = (size_t)a.pitch * a.rows;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (size_t)gridDim.x * blockDim.x) {
-        const int yy = (int)(i / a.pitch), xx = (int)(i % a.pitch);
-        a.plane[(size_t)blockIdx.y * a.plane_stride + i] =
-            load_rgbx(a.img[blockIdx.y], a.stride, a.ch, xx - a.apron_l, yy - a.rad + a.row0, a.w, a.h);
-    }
-}
-
-constexpr int kSadPadD = 16; // extra left apron of the R plane: the last chunk of DC
-                             // disparities may run past d_max (those costs are ignored)
-
 // ROWS = output rows per wave: 16 costs (16+WIN-1)/16 input rows per output row, 8 costs more
 // but gives small frames twice the waves
 // One wave per workgroup (round 3): a strip whose pixels are all decided by the threshold stops
@@ -88,12 +58,20 @@ constexpr int kSadPadD = 16; // extra left apron of the R plane: the last chunk 
 // was done -- five half-empty workgroups held a CU's LDS and nothing new could start (2.0 of 4
 // possible waves per SIMD resident, VALU 58 % busy; profiles/r3_sq_counters.txt).
 template <int WIN, int DC, int ROWS>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void sad_search_kernel(SadArgs a)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void sad_search_kernel(SadArgs a)
 {
     constexpr int RAD = WIN / 2;
     constexpr int kSadRows = ROWS;
     __shared__ uint32_t s_best[1][kSadRows][64]; // running min cost
     __shared__ uint32_t s_pick[1][kSadRows][64]; // bit 31: decided (under threshold); low: d
+    // the input row a step works on: every dword of it is fetched from memory ONCE per wave (one
+    // row ahead, behind the previous row's arithmetic) and handed to the lanes that need it
+    // through LDS -- a lane's WIN + DC+WIN-1 dwords used to be its own (merged) global loads,
+    // 25 dwords per lane where the wave's lanes need 151 distinct ones between them, issued and
+    // waited for at the top of every row with nothing to hide the latency but the other waves
+    constexpr int kRowL = 64 + WIN - 1, kRowR = 64 + DC + WIN - 1;
+    __shared__ uint32_t s_rowl[kRowL + 1], s_rowr[kRowR]; // (+ 1: where the lanes without a tail pixel write)
+    __shared__ uint32_t s_rawl[130], s_rawr[130]; // the rows' bytes as fetched (RGB or RGBA / RGB): <= 74 dwords, 2 x 64 written, + 2 read along
     const int lane = threadIdx.x & 63, wv = 0;
     // Workgroup ids go round-robin over the 8 XCDs, each with its own L2.  A wave reads the
     // right image's columns [x - d_max - RAD, x + 64 + RAD): two thirds of what its left
@@ -114,13 +92,36 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void sa
         s_best[wv][r][lane] = 0xffffffffu;
         s_pick[wv][r][lane] = 0u;
     }
-    // plane coordinates: image (x', y') sits at [y' - row0 + RAD][x' + apron_l] (the planes hold
-    // only the rows the strip [row0, row1) reads)
-    const uint32_t *lcol = a.lp + (size_t)f * a.lplane_stride + x; // + i  -> L(x - RAD + i)
+    // Row fetches.  The wave needs the columns [c_lo, c_hi] of a row (clamp-to-edge applied to
+    // its first and last column).  Lane i fetches the i-th ALIGNED dword from the one that holds
+    // the range's first byte on (the index capped at the dword of its last byte) and puts it at
+    // dword i of s_rawl / s_rawr: coalesced loads that touch nothing but dwords holding a byte of
+    // the range -- at an image's very first and last bytes that can be up to 3 bytes of the
+    // neighbouring allocation, inside the same aligned dword and therefore the same page, which
+    // are never used.  The lane that stages pixel jj then picks its three bytes out of the two
+    // dwords around byte m + (column(jj) - c_lo) * channels (m = how far the range's first byte
+    // sits inside its dword, a per-row scalar): ds_read2_b32 + v_alignbyte + mask = RGBX.
+    // (Unaligned 4-byte LDS accesses at a 3-byte stride do the same in one instruction and took
+    // 1.14 ms where the pre-packed planes took 0.68; per-pixel byte loads from memory 0.93.)
+    const uint8_t *limg = a.left[f], *rimg = a.right[f];
+    const uint32_t ulane = threadIdx.x & 63u;
+    const int x0 = (int)bcol * 64, wmax = (int)a.w - 1, hmax = (int)a.h - 1;
+    auto clampx = [&](int v) __attribute__((always_inline)) { return min(max(v, 0), wmax); };
+    // left image: staged index jj holds L(x0 + jj - RAD); lane -> jj = lane, lanes 32.. also jj = lane + 32
+    const int cl_lo = clampx(x0 - RAD), cl_hi = clampx(x0 + 63 + RAD);
+    const uint32_t nb_l = (uint32_t)(cl_hi - cl_lo + 1) * a.lch; // bytes of the range
+    const uint32_t base_l = (uint32_t)cl_lo * a.lch;
+    const uint32_t bo_l = (uint32_t)(clampx(x0 + lane - RAD) - cl_lo) * a.lch;
+    const uint32_t bo_lt = (uint32_t)(clampx(x0 + lane + 32 - RAD) - cl_lo) * a.lch;
     for (int d0 = 0; d0 < (int)a.d_max; d0 += DC) {
-        // + k -> R(x - RAD + i - d) with k = i + (DC-1-j), d = d0 + j
-        const uint32_t *rcol = a.rp + (size_t)f * a.rplane_stride + x + kSadPadD + ((int)a.d_max - 1) -
-                               d0 - (DC - 1);
+        // right image: staged index jj holds R(x0 + jj - RAD - d0 - (DC-1)): a lane's r[k] =
+        // staged[lane + k] = R(x - RAD + i - d) with k = i + (DC-1-j), d = d0 + j
+        const int rshift = RAD + d0 + (DC - 1);
+        const int cr_lo = clampx(x0 - rshift), cr_hi = clampx(x0 + 64 + DC + WIN - 3 - rshift);
+        const uint32_t nb_r = (uint32_t)(cr_hi - cr_lo + 1) * 3u;
+        const uint32_t base_r = (uint32_t)cr_lo * 3u;
+        const uint32_t bo_r = (uint32_t)(clampx(x0 + lane - rshift) - cr_lo) * 3u;
+        const uint32_t bo_rt = (uint32_t)(clampx(x0 + lane + 64 - rshift) - cr_lo) * 3u;
         uint32_t cost[DC], ring[WIN][DC];
 #pragma unroll
         for (int j = 0; j < DC; ++j) {
@@ -129,22 +130,109 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void sa
             for (int s = 0; s < WIN; ++s)
                 ring[s][j] = 0;
         }
-        // input rows ys-RAD .. ys+nrows-1+RAD, i.e. plane rows ys-row0 .. ys-row0+nrows-1+2*RAD
+        // input rows ys-RAD .. ys+nrows-1+RAD (clamped to the image)
         const int n_in = nrows + 2 * RAD;
+        // staging: every lane its own column of either image, and one pixel of the columns beyond
+        // the wave's 64 (lanes 0..DC+WIN-3: right image, the WIN-1 lanes from 32 on: left image;
+        // the other lanes stage a pixel into a slot nobody reads: straight-line code)
+        static_assert(DC + WIN - 2 <= 32 && WIN - 1 <= 32, "the tail lanes");
+        const bool tail_r = ulane < (uint32_t)(DC + WIN - 2), tail_l = ulane >= 32u && ulane < 32u + (uint32_t)(WIN - 1);
+        const uint32_t *raw_t = tail_r ? s_rawr : s_rawl;
+        const uint32_t bo_t = tail_r ? bo_rt : tail_l ? bo_lt : 0u;
+        uint32_t *dst_t = tail_r ? &s_rowr[64u + ulane] : tail_l ? &s_rowl[32u + ulane] : &s_rowl[kRowL];
+        // m = how far a row's range starts inside its first dword.  With row pitches that are
+        // multiples of 4 -- the usual case -- it is the same for every row and everything that
+        // depends on it is worked out once per chunk.
+        const bool same_m = ((a.lstride | a.rstride) & 3u) == 0u; // uniform
+        uint32_t pl = 0, pr = 0, pl2 = 0, pr2 = 0;
+        uint32_t m_l, m_r, m_ln, m_rn, il, ir, il2, ir2, last_l, last_r;
+        const uint32_t *qa, *qb, *qc; // the dword pairs around this lane's pixels in the raw rows
+        uint32_t sh_l, sh_r, sh_t;
+        auto set_m = [&](uint32_t ml, uint32_t mr) __attribute__((always_inline)) {
+            m_ln = ml;
+            m_rn = mr;
+            last_l = (ml + nb_l - 1u) >> 2; // the ranges' last dwords
+            last_r = (mr + nb_r - 1u) >> 2;
+            il = min(ulane, last_l);
+            ir = min(ulane, last_r);
+            il2 = min(64u + ulane, last_l);
+            ir2 = min(64u + ulane, last_r);
+        };
+        auto use_m = [&]() __attribute__((always_inline)) {
+            m_l = m_ln;
+            m_r = m_rn;
+            sh_l = m_l + bo_l;
+            sh_r = m_r + bo_r;
+            sh_t = (tail_r ? m_r : m_l) + bo_t;
+            qa = s_rawl + (sh_l >> 2);
+            qb = s_rawr + (sh_r >> 2);
+            qc = raw_t + (sh_t >> 2);
+        };
+        auto row_addr = [&](int t, uintptr_t &la, uintptr_t &ra) __attribute__((always_inline)) {
+            const int yy = min(max(ys - RAD + t, 0), hmax); // uniform
+            la = reinterpret_cast<uintptr_t>(limg) + (size_t)yy * a.lstride + base_l;
+            ra = reinterpret_cast<uintptr_t>(rimg) + (size_t)yy * a.rstride + base_r;
+        };
+        auto fetch = [&](int t) __attribute__((always_inline)) {
+            uintptr_t la, ra;
+            row_addr(t, la, ra);
+            if (!same_m)
+                set_m((uint32_t)la & 3u, (uint32_t)ra & 3u);
+            const uint32_t *lq = reinterpret_cast<const uint32_t *>(la - m_ln), *rq = reinterpret_cast<const uint32_t *>(ra - m_rn);
+            pl = lq[il];
+            pr = rq[ir];
+            if (last_l >= 64u) // uniform; RGBA rows only
+                pl2 = lq[il2];
+            if (last_r >= 64u) // uniform
+                pr2 = rq[ir2];
+        };
+        {
+            uintptr_t la, ra;
+            row_addr(0, la, ra);
+            set_m((uint32_t)la & 3u, (uint32_t)ra & 3u);
+            use_m();
+        }
+        fetch(0);
         for (int t0 = 0; t0 < n_in; t0 += WIN) {
 #pragma unroll
             for (int s = 0; s < WIN; ++s) {
                 const int t = t0 + s;
                 if (t < n_in) { // uniform
-                    const uint32_t *lr = lcol + (size_t)(ys - (int)a.row0 + t) * a.lpitch;
-                    const uint32_t *rr = rcol + (size_t)(ys - (int)a.row0 + t) * a.rpitch;
+                    // (the previous row's reads are done: LDS operations of a wave complete in
+                    // program order; the barriers keep the compiler from moving a lane's reads
+                    // of OTHER lanes' bytes across its own writes)
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    s_rawl[ulane] = pl;
+                    s_rawr[ulane] = pr;
+                    if (last_l >= 64u)
+                        s_rawl[64u + ulane] = pl2;
+                    if (last_r >= 64u)
+                        s_rawr[64u + ulane] = pr2;
+                    if (!same_m)
+                        use_m();
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    if (t + 1 < n_in)
+                        fetch(t + 1); // lands while this row is worked on
+                    {
+                        // the three bytes of each pixel out of the dword pair around them
+                        const uint32_t vl = __builtin_amdgcn_alignbyte(qa[1], qa[0], sh_l) & 0xFFFFFFu;
+                        const uint32_t vr = __builtin_amdgcn_alignbyte(qb[1], qb[0], sh_r) & 0xFFFFFFu;
+                        const uint32_t vt = __builtin_amdgcn_alignbyte(qc[1], qc[0], sh_t) & 0xFFFFFFu;
+                        s_rowl[ulane] = vl;
+                        s_rowr[ulane] = vr;
+                        *dst_t = vt;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
                     uint32_t l[WIN], r[DC + WIN - 1];
 #pragma unroll
                     for (int i = 0; i < WIN; ++i)
-                        l[i] = lr[i];
+                        l[i] = s_rowl[ulane + i];
 #pragma unroll
                     for (int k = 0; k < DC + WIN - 1; ++k)
-                        r[k] = rr[k];
+                        r[k] = s_rowr[ulane + k];
 #pragma unroll
                     for (int j = 0; j < DC; ++j) {
                         // the sad chain accumulates straight into the sum of the horizontal window
@@ -293,41 +381,6 @@ __global__ __launch_bounds__(256) void sad_match_kernel(SadArgs a)
 }
 
 inline bool sad_has_fast_path(uint32_t win) { return win == 3 || win == 5 || win == 7 || win == 9; }
-
-inline void sad_plane_dims(const SadArgs &a, bool right, uint32_t &pitch, uint32_t &rows,
-                           int &apron_l)
-{
-    const int rad = (int)a.win / 2;
-    apron_l = rad + (right ? (int)a.d_max - 1 + kSadPadD : 0);
-    pitch = (uint32_t)(apron_l + (int)((a.w + 63u) / 64u * 64u) + rad + 64);
-    rows = (a.row1 - a.row0) + 2u * (uint32_t)rad; // only what the strip [row0,row1) reads
-}
-
-// pack both planes; a.lp/a.rp/pitches must already be set
-inline int launch_sad_pack(const SadArgs &a, hipStream_t stream)
-{
-    for (int side = 0; side < 2; ++side) {
-        SadPackArgs p{};
-        for (uint32_t f = 0; f < a.n_frames; ++f)
-            p.img[f] = side ? a.right[f] : a.left[f];
-        p.plane_stride = side ? a.rplane_stride : a.lplane_stride;
-        p.stride = side ? a.rstride : a.lstride;
-        p.ch = side ? 3u : a.lch;
-        p.w = a.w;
-        p.h = a.h;
-        p.rad = (int)a.win / 2;
-        p.row0 = (int)a.row0;
-        uint32_t pitch, rows;
-        sad_plane_dims(a, side != 0, pitch, rows, p.apron_l);
-        p.pitch = pitch;
-        p.rows = rows;
-        p.plane = side ? a.rp : a.lp;
-        const size_t total = (size_t)pitch * rows;
-        const uint32_t blocks = (uint32_t)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-        hipLaunchKernelGGL(sad_pack_kernel, dim3(blocks, a.n_frames), dim3(256), 0, stream, p);
-    }
-    return hipGetLastError() == hipSuccess ? 0 : -3;
-}
 
 inline int launch_sad(const SadArgs &a_in, hipStream_t stream)
 {

@@ -14,7 +14,13 @@ while time.time()-t0 < float(sys.argv[2] if len(sys.argv)>2 else 90):
     want=[O.sad_rows(l,r,dmax,win,prec)[r0:r1] for l,r in zip(L,R)]
     dev=rng.random()<0.5
     if dev:
-        outs,mx=eng.depth_from_additional_batch([torch.from_numpy(l).cuda() for l in L],[torch.from_numpy(r).cuda() for r in R],prec,mode=MODE_SAD_WINDOW,d_max=dmax,win=win,raw_only=True,rows=(r0,r1))
+        # device images at any byte alignment (views into larger buffers), the main one RGB or RGBA
+        rgba=rng.random()<0.3; offs=[int(v) for v in rng.integers(0,4,2)]
+        def view(a,off):
+            b=torch.zeros(a.size+off+int(rng.integers(0,3)),dtype=torch.uint8,device="cuda")
+            v=b[off:off+a.size].view(*a.shape); v.copy_(torch.from_numpy(a)); return v
+        Lm=[np.concatenate([l,rng.integers(0,256,(h,w,1),dtype=np.uint8)],axis=2) if rgba else l for l in L]
+        outs,mx=eng.depth_from_additional_batch([view(l,offs[0]) for l in Lm],[view(r,offs[1]) for r in R],prec,mode=MODE_SAD_WINDOW,d_max=dmax,win=win,raw_only=True,rows=(r0,r1))
         got=[o.cpu().numpy()[r0:r1] for o in outs]
     else:
         outs,mx=eng.depth_from_additional_batch(L,R,prec,mode=MODE_SAD_WINDOW,d_max=dmax,win=win,raw_only=True,rows=(r0,r1))

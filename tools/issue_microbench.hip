@@ -39,7 +39,7 @@
     "s_and_b64 %0, %0, %4\n s_ff1_i32_b64 %2, %0\n s_or_b64 %1, %1, %4\n s_bcnt1_i32_b64 %3, %1\n" \
     "s_andn2_b64 %0, %0, %4\n s_ff1_i32_b64 %2, %1\n s_xor_b64 %1, %1, %4\n s_bcnt1_i32_b64 %3, %0\n"
 
-enum Kind { K_VALU, K_SALU, K_MIX, K_SALU64, K_CMP_READLANE, K_MIX_HALF, K_ADD64, K_ADD64_SGPR, K_SAD_U8, K_QSAD, K_MQSAD, K_PK_ADD_U16 };
+enum Kind { K_VALU, K_SALU, K_MIX, K_SALU64, K_CMP_READLANE, K_MIX_HALF, K_ADD64, K_ADD64_SGPR, K_SAD_U8, K_QSAD, K_MQSAD, K_PK_ADD_U16, K_VALU_Q1, K_VALU_H1, K_VALU_S16 };
 
 template <int KIND>
 __global__ __launch_bounds__(256) void issue_kernel(uint32_t iters, uint32_t *out,
@@ -58,6 +58,23 @@ __global__ __launch_bounds__(256) void issue_kernel(uint32_t iters, uint32_t *ou
                        w6 = w0 + 6, w7 = w0 + 7;
     const unsigned long long wk = 0x0000010100000303ull + iters;
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    // partly filled waves: does a wave64 VALU instruction get cheaper when whole quarters (the
+    // SIMD's 16-lane passes) or halves of EXEC are off?  Q1: lanes 0..15, H1: lanes 0..31,
+    // S16: every fourth lane (16 lanes spread over all four passes)
+    if constexpr (KIND == K_VALU_Q1 || KIND == K_VALU_H1 || KIND == K_VALU_S16) {
+        const uint32_t ln = threadIdx.x & 63u;
+        const bool act = KIND == K_VALU_Q1 ? ln < 16u : KIND == K_VALU_H1 ? ln < 32u : (ln & 3u) == 0u;
+        if (act) {
+            for (uint32_t i = 0; i < iters; ++i) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    asm volatile(VALU8
+                                 : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5),
+                                   "+v"(v6), "+v"(v7)
+                                 : "v"(va), "v"(vb));
+            }
+        }
+    } else
     for (uint32_t i = 0; i < iters; ++i) {
         if constexpr (KIND == K_VALU) {
 #pragma unroll
@@ -243,6 +260,9 @@ int main()
         if (run<K_QSAD>("v_qsad_pk_u16", w, 32, 0, cus)) return 1;
         if (run<K_MQSAD>("v_mqsad_pk_u16", w, 32, 0, cus)) return 1;
         if (run<K_PK_ADD_U16>("v_pk_add_u16", w, 32, 0, cus)) return 1;
+        if (run<K_VALU_Q1>("valu lanes0-15", w, 32, 0, cus)) return 1;
+        if (run<K_VALU_H1>("valu lanes0-31", w, 32, 0, cus)) return 1;
+        if (run<K_VALU_S16>("valu 16 spread", w, 32, 0, cus)) return 1;
     }
     return 0;
 }
