@@ -64,14 +64,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void sa
     constexpr int kSadRows = ROWS;
     __shared__ uint32_t s_best[1][kSadRows][64]; // running min cost
     __shared__ uint32_t s_pick[1][kSadRows][64]; // bit 31: decided (under threshold); low: d
-    // the input row a step works on: every dword of it is fetched from memory ONCE per wave (one
+    // the input row a step works on: every pixel of it is fetched from memory ONCE per wave (one
     // row ahead, behind the previous row's arithmetic) and handed to the lanes that need it
-    // through LDS -- a lane's WIN + DC+WIN-1 dwords used to be its own (merged) global loads,
-    // 25 dwords per lane where the wave's lanes need 151 distinct ones between them, issued and
-    // waited for at the top of every row with nothing to hide the latency but the other waves
+    // through LDS -- a lane's WIN + DC+WIN-1 RGBX dwords used to be its own (merged) loads from
+    // pre-packed planes, 25 dwords per lane where the wave's lanes need 151 distinct ones between
+    // them, issued and waited for at the top of every row with nothing to hide the latency but the
+    // other waves
     constexpr int kRowL = 64 + WIN - 1, kRowR = 64 + DC + WIN - 1;
     __shared__ uint32_t s_rowl[kRowL + 1], s_rowr[kRowR]; // (+ 1: where the lanes without a tail pixel write)
-    __shared__ uint32_t s_rawl[130], s_rawr[130]; // the rows' bytes as fetched (RGB or RGBA / RGB): <= 74 dwords, 2 x 64 written, + 2 read along
     const int lane = threadIdx.x & 63, wv = 0;
     // Workgroup ids go round-robin over the 8 XCDs, each with its own L2.  A wave reads the
     // right image's columns [x - d_max - RAD, x + 64 + RAD): two thirds of what its left
@@ -92,36 +92,33 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void sa
         s_best[wv][r][lane] = 0xffffffffu;
         s_pick[wv][r][lane] = 0u;
     }
-    // Row fetches.  The wave needs the columns [c_lo, c_hi] of a row (clamp-to-edge applied to
-    // its first and last column).  Lane i fetches the i-th ALIGNED dword from the one that holds
-    // the range's first byte on (the index capped at the dword of its last byte) and puts it at
-    // dword i of s_rawl / s_rawr: coalesced loads that touch nothing but dwords holding a byte of
-    // the range -- at an image's very first and last bytes that can be up to 3 bytes of the
-    // neighbouring allocation, inside the same aligned dword and therefore the same page, which
-    // are never used.  The lane that stages pixel jj then picks its three bytes out of the two
-    // dwords around byte m + (column(jj) - c_lo) * channels (m = how far the range's first byte
-    // sits inside its dword, a per-row scalar): ds_read2_b32 + v_alignbyte + mask = RGBX.
-    // (Unaligned 4-byte LDS accesses at a 3-byte stride do the same in one instruction and took
-    // 1.14 ms where the pre-packed planes took 0.68; per-pixel byte loads from memory 0.93.)
+    // Row fetches.  The lane that stages pixel jj of a row fetches the pixel itself, one row
+    // ahead of the arithmetic: the ALIGNED dword that holds its first byte and the one that holds
+    // its last (the same dword again when the three bytes do not straddle two) -- loads that touch
+    // nothing but dwords holding a byte of the pixel: at an image's very first and last bytes
+    // that can be up to 3 bytes of the neighbouring allocation, inside the same aligned dword and
+    // therefore the same page, which are never used.  v_alignbyte + mask turn the pair into the
+    // RGBX dword that goes to LDS.  Clamp-to-edge is a per-lane, per-chunk column and a scalar
+    // row clamp; the byte offsets only depend on the row when the pitches are not multiples of 4.
+    // (Measured on the way, 4 x 4K 5x5 d_max 128, search kernel ms: pre-packed RGBX planes with
+    // per-lane loads 0.694 (+ 0.142 for the pack kernel), the planes staged through LDS 0.676,
+    // byte loads per pixel 0.935, the rows' raw dwords through LDS and unaligned 4-byte LDS reads
+    // at a 3-byte stride 1.142, the same with aligned dword pairs 0.794, this scheme with
+    // per-lane 64-bit addresses 0.775, with scalar row bases + 32-bit offsets 0.718.)
     const uint8_t *limg = a.left[f], *rimg = a.right[f];
     const uint32_t ulane = threadIdx.x & 63u;
     const int x0 = (int)bcol * 64, wmax = (int)a.w - 1, hmax = (int)a.h - 1;
     auto clampx = [&](int v) __attribute__((always_inline)) { return min(max(v, 0), wmax); };
     // left image: staged index jj holds L(x0 + jj - RAD); lane -> jj = lane, lanes 32.. also jj = lane + 32
-    const int cl_lo = clampx(x0 - RAD), cl_hi = clampx(x0 + 63 + RAD);
-    const uint32_t nb_l = (uint32_t)(cl_hi - cl_lo + 1) * a.lch; // bytes of the range
-    const uint32_t base_l = (uint32_t)cl_lo * a.lch;
-    const uint32_t bo_l = (uint32_t)(clampx(x0 + lane - RAD) - cl_lo) * a.lch;
-    const uint32_t bo_lt = (uint32_t)(clampx(x0 + lane + 32 - RAD) - cl_lo) * a.lch;
+    const uint32_t co_l = (uint32_t)clampx(x0 + lane - RAD) * a.lch;       // byte offsets in a row
+    const uint32_t co_lt = (uint32_t)clampx(x0 + lane + 32 - RAD) * a.lch;
+    const bool same_m = ((a.lstride | a.rstride) & 3u) == 0u; // uniform: a row's alignment is every row's
     for (int d0 = 0; d0 < (int)a.d_max; d0 += DC) {
         // right image: staged index jj holds R(x0 + jj - RAD - d0 - (DC-1)): a lane's r[k] =
         // staged[lane + k] = R(x - RAD + i - d) with k = i + (DC-1-j), d = d0 + j
         const int rshift = RAD + d0 + (DC - 1);
-        const int cr_lo = clampx(x0 - rshift), cr_hi = clampx(x0 + 64 + DC + WIN - 3 - rshift);
-        const uint32_t nb_r = (uint32_t)(cr_hi - cr_lo + 1) * 3u;
-        const uint32_t base_r = (uint32_t)cr_lo * 3u;
-        const uint32_t bo_r = (uint32_t)(clampx(x0 + lane - rshift) - cr_lo) * 3u;
-        const uint32_t bo_rt = (uint32_t)(clampx(x0 + lane + 64 - rshift) - cr_lo) * 3u;
+        const uint32_t co_r = (uint32_t)clampx(x0 + lane - rshift) * 3u;
+        const uint32_t co_rt = (uint32_t)clampx(x0 + lane + 64 - rshift) * 3u;
         uint32_t cost[DC], ring[WIN][DC];
 #pragma unroll
         for (int j = 0; j < DC; ++j) {
@@ -137,61 +134,51 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void sa
         // the other lanes stage a pixel into a slot nobody reads: straight-line code)
         static_assert(DC + WIN - 2 <= 32 && WIN - 1 <= 32, "the tail lanes");
         const bool tail_r = ulane < (uint32_t)(DC + WIN - 2), tail_l = ulane >= 32u && ulane < 32u + (uint32_t)(WIN - 1);
-        const uint32_t *raw_t = tail_r ? s_rawr : s_rawl;
-        const uint32_t bo_t = tail_r ? bo_rt : tail_l ? bo_lt : 0u;
+        const uint32_t co_t = tail_r ? co_rt : tail_l ? co_lt : co_l;
         uint32_t *dst_t = tail_r ? &s_rowr[64u + ulane] : tail_l ? &s_rowl[32u + ulane] : &s_rowl[kRowL];
-        // m = how far a row's range starts inside its first dword.  With row pitches that are
-        // multiples of 4 -- the usual case -- it is the same for every row and everything that
-        // depends on it is worked out once per chunk.
-        const bool same_m = ((a.lstride | a.rstride) & 3u) == 0u; // uniform
-        uint32_t pl = 0, pr = 0, pl2 = 0, pr2 = 0;
-        uint32_t m_l, m_r, m_ln, m_rn, il, ir, il2, ir2, last_l, last_r;
-        const uint32_t *qa, *qb, *qc; // the dword pairs around this lane's pixels in the raw rows
-        uint32_t sh_l, sh_r, sh_t;
+        // per pixel: dword index of its first byte and of its last, and the shift (from an aligned
+        // base <= 3 bytes before the row)
+        uint32_t m_l = 0, m_r = 0; // uniform: how far the rows start inside a dword
+        uint32_t i0_l, i1_l, sh_l, i0_r, i1_r, sh_r, i0_t, i1_t, sh_t;
+        auto place = [](uint32_t o, uint32_t &i0, uint32_t &i1, uint32_t &sh) __attribute__((always_inline)) {
+            i0 = o & ~3u;              // byte offsets of the two dwords (32-bit: the loads below are
+            i1 = i0 + ((o & 2u) << 1); // scalar base + vector offset); bytes o..o+2 reach into the
+            sh = o;                    // next dword iff o & 3 >= 2
+        };
         auto set_m = [&](uint32_t ml, uint32_t mr) __attribute__((always_inline)) {
-            m_ln = ml;
-            m_rn = mr;
-            last_l = (ml + nb_l - 1u) >> 2; // the ranges' last dwords
-            last_r = (mr + nb_r - 1u) >> 2;
-            il = min(ulane, last_l);
-            ir = min(ulane, last_r);
-            il2 = min(64u + ulane, last_l);
-            ir2 = min(64u + ulane, last_r);
+            m_l = ml;
+            m_r = mr;
+            place(ml + co_l, i0_l, i1_l, sh_l);
+            place(mr + co_r, i0_r, i1_r, sh_r);
+            place((tail_r ? mr : ml) + co_t, i0_t, i1_t, sh_t);
         };
-        auto use_m = [&]() __attribute__((always_inline)) {
-            m_l = m_ln;
-            m_r = m_rn;
-            sh_l = m_l + bo_l;
-            sh_r = m_r + bo_r;
-            sh_t = (tail_r ? m_r : m_l) + bo_t;
-            qa = s_rawl + (sh_l >> 2);
-            qb = s_rawr + (sh_r >> 2);
-            qc = raw_t + (sh_t >> 2);
-        };
-        auto row_addr = [&](int t, uintptr_t &la, uintptr_t &ra) __attribute__((always_inline)) {
-            const int yy = min(max(ys - RAD + t, 0), hmax); // uniform
-            la = reinterpret_cast<uintptr_t>(limg) + (size_t)yy * a.lstride + base_l;
-            ra = reinterpret_cast<uintptr_t>(rimg) + (size_t)yy * a.rstride + base_r;
+        uint32_t pl0 = 0, pl1 = 0, pr0 = 0, pr1 = 0, pt0 = 0, pt1 = 0; // the row in flight
+        uint32_t fl, fr, ft;                                             // its shifts
+        auto dword_at = [](const uint8_t *base, uint32_t off) __attribute__((always_inline)) -> uint32_t {
+            return *reinterpret_cast<const uint32_t *>(base + off);
         };
         auto fetch = [&](int t) __attribute__((always_inline)) {
-            uintptr_t la, ra;
-            row_addr(t, la, ra);
+            const int yy = min(max(ys - RAD + t, 0), hmax); // uniform
+            const uint8_t *la = limg + (size_t)yy * a.lstride, *ra = rimg + (size_t)yy * a.rstride;
             if (!same_m)
-                set_m((uint32_t)la & 3u, (uint32_t)ra & 3u);
-            const uint32_t *lq = reinterpret_cast<const uint32_t *>(la - m_ln), *rq = reinterpret_cast<const uint32_t *>(ra - m_rn);
-            pl = lq[il];
-            pr = rq[ir];
-            if (last_l >= 64u) // uniform; RGBA rows only
-                pl2 = lq[il2];
-            if (last_r >= 64u) // uniform
-                pr2 = rq[ir2];
+                set_m((uint32_t)reinterpret_cast<uintptr_t>(la) & 3u, (uint32_t)reinterpret_cast<uintptr_t>(ra) & 3u);
+            const uint8_t *lq = la - m_l, *rq = ra - m_r; // aligned, uniform
+            pl0 = dword_at(lq, i0_l);
+            pl1 = dword_at(lq, i1_l);
+            pr0 = dword_at(rq, i0_r);
+            pr1 = dword_at(rq, i1_r);
+            if (tail_r) { // (measured equal as two masked pairs)
+                pt0 = dword_at(rq, i0_t);
+                pt1 = dword_at(rq, i1_t);
+            } else {
+                pt0 = dword_at(lq, i0_t);
+                pt1 = dword_at(lq, i1_t);
+            }
+            fl = sh_l;
+            fr = sh_r;
+            ft = sh_t;
         };
-        {
-            uintptr_t la, ra;
-            row_addr(0, la, ra);
-            set_m((uint32_t)la & 3u, (uint32_t)ra & 3u);
-            use_m();
-        }
+        set_m((uint32_t)reinterpret_cast<uintptr_t>(limg) & 3u, (uint32_t)reinterpret_cast<uintptr_t>(rimg) & 3u);
         fetch(0);
         for (int t0 = 0; t0 < n_in; t0 += WIN) {
 #pragma unroll
@@ -200,32 +187,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void sa
                 if (t < n_in) { // uniform
                     // (the previous row's reads are done: LDS operations of a wave complete in
                     // program order; the barriers keep the compiler from moving a lane's reads
-                    // of OTHER lanes' bytes across its own writes)
+                    // of OTHER lanes' pixels across its own writes)
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
-                    s_rawl[ulane] = pl;
-                    s_rawr[ulane] = pr;
-                    if (last_l >= 64u)
-                        s_rawl[64u + ulane] = pl2;
-                    if (last_r >= 64u)
-                        s_rawr[64u + ulane] = pr2;
-                    if (!same_m)
-                        use_m();
+                    s_rowl[ulane] = __builtin_amdgcn_alignbyte(pl1, pl0, fl) & 0xFFFFFFu;
+                    s_rowr[ulane] = __builtin_amdgcn_alignbyte(pr1, pr0, fr) & 0xFFFFFFu;
+                    *dst_t = __builtin_amdgcn_alignbyte(pt1, pt0, ft) & 0xFFFFFFu;
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     if (t + 1 < n_in)
                         fetch(t + 1); // lands while this row is worked on
-                    {
-                        // the three bytes of each pixel out of the dword pair around them
-                        const uint32_t vl = __builtin_amdgcn_alignbyte(qa[1], qa[0], sh_l) & 0xFFFFFFu;
-                        const uint32_t vr = __builtin_amdgcn_alignbyte(qb[1], qb[0], sh_r) & 0xFFFFFFu;
-                        const uint32_t vt = __builtin_amdgcn_alignbyte(qc[1], qc[0], sh_t) & 0xFFFFFFu;
-                        s_rowl[ulane] = vl;
-                        s_rowr[ulane] = vr;
-                        *dst_t = vt;
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
                     uint32_t l[WIN], r[DC + WIN - 1];
 #pragma unroll
                     for (int i = 0; i < WIN; ++i)
