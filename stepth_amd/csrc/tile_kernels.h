@@ -247,8 +247,9 @@ __device__ __forceinline__ void ring_tile_body(const TileArgs &a, const uint32_t
                     if ((uint32_t)square_dmin(x0, y0, 8) < tq.limit) {
                         const uint32_t boff = tf + ((uint32_t)by * a.bw + (uint32_t)bx) * 64u;
                         const uint32_t best_before = tq.best;
-                        const uint32_t nl = probe_block(tq, x0, y0, pb, a.T + boff, a.TT + boff,
-                                                        reinterpret_cast<const uint32_t *>(a.LB) + (boff >> 1), &pcnt);
+                        const uint32_t nl = probe_block(tq, x0, y0, pb, reinterpret_cast<const uint8_t *>(a.T),
+                                                        reinterpret_cast<const uint8_t *>(a.TT),
+                                                        reinterpret_cast<const uint8_t *>(a.LB), boff << 2, &pcnt);
                         if (tq.best < best_before) {
                             atomicMin(&s_best[lw][src], tq.best);
                             atomicMin(&s_lim[lw][src], tq.limit);
@@ -492,8 +493,9 @@ __device__ __forceinline__ void ring_tile_body(const TileArgs &a, const uint32_t
                         const uint32_t boff = tf + ((uint32_t)by * a.bw + (uint32_t)bx) * 64u;
                         [[maybe_unused]] const uint32_t best_before = q.best;
                         const uint32_t nl =
-                            probe_block(q, x0, y0, pb, a.T + boff, a.TT + boff,
-                                        reinterpret_cast<const uint32_t *>(a.LB) + (boff >> 1), &pcnt);
+                            probe_block(q, x0, y0, pb, reinterpret_cast<const uint8_t *>(a.T),
+                                        reinterpret_cast<const uint8_t *>(a.TT),
+                                        reinterpret_cast<const uint8_t *>(a.LB), boff << 2, &pcnt);
                         if constexpr (STATS) {
                             ++n_probed;
                             n_tests += 8u * nl;
@@ -1244,8 +1246,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                                 if ((uint32_t)square_dmin(x0, y0, 8) < tq.limit) {
                                     const uint32_t boff = tf + ((uint32_t)by * a.bw + (uint32_t)bx) * 64u;
                                     const uint32_t best_before = tq.best;
-                                    const uint32_t nl = probe_block(tq, x0, y0, pb, a.T + boff, a.TT + boff,
-                                                                    reinterpret_cast<const uint32_t *>(a.LB) + (boff >> 1));
+                                    const uint32_t nl = probe_block(tq, x0, y0, pb, reinterpret_cast<const uint8_t *>(a.T),
+                                                                    reinterpret_cast<const uint8_t *>(a.TT),
+                                                                    reinterpret_cast<const uint8_t *>(a.LB), boff << 2);
                                     if (tq.best < best_before) {
                                         atomicMin(&s_best[wv][src], tq.best);
                                         atomicMin(&s_lim[wv][src], tq.limit);

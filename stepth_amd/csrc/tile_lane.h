@@ -148,8 +148,9 @@ struct LineTest {
 // the block, lb = {max,min} bounds of the 8 lines (rows for sides 0/1, columns for 2/3): only
 // a line whose bounds meet the box is read.  Returns the lines read.
 template <int SIDE>
-STEPTH_HD uint32_t scan_side(LaneQ &q, int a0, int b0, int mdb, uint32_t pb, const uint32_t *tbl,
-                             const uint32_t *lb, [[maybe_unused]] ProbeCounters *pc = nullptr)
+STEPTH_HD uint32_t scan_side(LaneQ &q, int a0, int b0, int mdb, uint32_t pb, const uint8_t *tbl_base,
+                             uint32_t tbl_off, const uint8_t *lb_base, uint32_t lb_off,
+                             [[maybe_unused]] ProbeCounters *pc = nullptr)
 {
     STEPTH_CNT(pc, 2);
     constexpr bool neg = SIDE & 1;
@@ -165,7 +166,7 @@ STEPTH_HD uint32_t scan_side(LaneQ &q, int a0, int b0, int mdb, uint32_t pb, con
     {
 #if defined(__HIP_DEVICE_COMPILE__)
         // the 8 {max, min} pairs as 64-bit values, highest scan index first (bound_bit)
-        const ulonglong2 *l2 = reinterpret_cast<const ulonglong2 *>(lb);
+        const ulonglong2 *l2 = reinterpret_cast<const ulonglong2 *>(lb_base + lb_off);
         const ulonglong2 w0 = l2[0], w1 = l2[1], w2 = l2[2], w3 = l2[3];
         const uint64_t k = ((uint64_t)q.hi << 32) | q.lo;
         const uint64_t w[8] = {w0.x, w0.y, w1.x, w1.y, w2.x, w2.y, w3.x, w3.y};
@@ -173,6 +174,7 @@ STEPTH_HD uint32_t scan_side(LaneQ &q, int a0, int b0, int mdb, uint32_t pb, con
         for (int i = 7; i >= 0; --i)
             cand = bound_bit(cand, w[neg ? 7 - i : i], k);
 #else
+        const uint32_t *lb = reinterpret_cast<const uint32_t *>(lb_base + lb_off);
         for (int i = 7; i >= 0; --i) { // highest scan index first: it ends in the highest bit
             const int l = neg ? 7 - i : i;
             cand = cand + cand + (box_meets(lb[2 * l], lb[2 * l + 1], q.lo, q.hi) ? 1u : 0u);
@@ -190,7 +192,7 @@ STEPTH_HD uint32_t scan_side(LaneQ &q, int a0, int b0, int mdb, uint32_t pb, con
             break;
         const int line = neg ? 7 - i : i;
         LineTest t;
-        t.load(tbl + line * 8, q.lo, q.hi);
+        t.load(reinterpret_cast<const uint32_t *>(tbl_base + (tbl_off + (uint32_t)line * 32u)), q.lo, q.hi);
         ++n_lines;
         STEPTH_CNT(pc, 4);
         if (t.any()) {
@@ -213,19 +215,22 @@ STEPTH_HD uint32_t scan_side(LaneQ &q, int a0, int b0, int mdb, uint32_t pb, con
 }
 
 // Examines one block for query q.  (x0, y0) = offset of the block's cell (0,0) from the
-// centre; rows / cols = its 64 cells row-major (T) and column-major (TT); lb = its 16 line
-// bounds (8 rows, then 8 columns; uint2 {max,min} each); pb = position bits of the key.
-// Returns the number of lines read (statistics).
-STEPTH_HD uint32_t probe_block(LaneQ &q, int x0, int y0, uint32_t pb, const uint32_t *rows,
-                               const uint32_t *cols, const uint32_t *lb,
+// centre.  The tables arrive as their (wave-uniform) bases and the block's 32-bit BYTE offset
+// `off`: its 64 cells row-major at T + off, column-major at TT + off, its 16 line bounds (8 rows,
+// then 8 columns; uint2 {max,min} each) at LB + off / 2 -- every load is then scalar base + vector
+// offset, no per-lane 64-bit pointer is formed or kept (the whole of T is < 2^32 bytes, engine.hip).
+// pb = position bits of the key.  Returns the number of lines read (statistics).
+STEPTH_HD uint32_t probe_block(LaneQ &q, int x0, int y0, uint32_t pb, const uint8_t *T,
+                               const uint8_t *TT, const uint8_t *LB, uint32_t off,
                                [[maybe_unused]] ProbeCounters *pc = nullptr)
 {
     STEPTH_CNT(pc, 1);
     const int mdx = imax(imax(x0, -(x0 + 7)), 0), mdy = imax(imax(y0, -(y0 + 7)), 0);
-    uint32_t n = scan_side<0>(q, y0, x0, mdx, pb, rows, lb, pc);
-    n += scan_side<1>(q, y0, x0, mdx, pb, rows, lb, pc);
-    n += scan_side<2>(q, x0, y0, mdy, pb, cols, lb + 16, pc);
-    n += scan_side<3>(q, x0, y0, mdy, pb, cols, lb + 16, pc);
+    const uint32_t lbo = off >> 1;
+    uint32_t n = scan_side<0>(q, y0, x0, mdx, pb, T, off, LB, lbo, pc);
+    n += scan_side<1>(q, y0, x0, mdx, pb, T, off, LB, lbo, pc);
+    n += scan_side<2>(q, x0, y0, mdy, pb, TT, off, LB, lbo + 64u, pc);
+    n += scan_side<3>(q, x0, y0, mdy, pb, TT, off, LB, lbo + 64u, pc);
     return n;
 }
 

@@ -198,8 +198,8 @@ extern "C" int tile_emulate(const uint8_t *main_px, uint32_t W, uint32_t H, uint
                                         return;
                                     }
                                     const size_t boff = ((size_t)t.by * bw + t.bx) * 64;
-                                    n_lines += probe_block(tq, x0, y0, pb, &T[boff], &TT[boff],
-                                                           reinterpret_cast<const uint32_t *>(&LB[boff / 4]));
+                                    n_lines += probe_block(tq, x0, y0, pb, reinterpret_cast<const uint8_t *>(T.data()), reinterpret_cast<const uint8_t *>(TT.data()),
+                                                           reinterpret_cast<const uint8_t *>(LB.data()), (uint32_t)(boff * 4));
                                     ++n_probes;
                                 }
                                 res[i] = tq;
@@ -347,8 +347,8 @@ extern "C" int tile_emulate(const uint8_t *main_px, uint32_t W, uint32_t H, uint
                                         if (bx < 0 || by < 0 || bx >= (int)bw || by >= (int)bh)
                                             return -2; // a padded block got through: memory fault on the GPU
                                         const size_t boff = ((size_t)by * bw + bx) * 64;
-                                        n_lines += probe_block(q[l], x0, y0, pb, &T[boff], &TT[boff],
-                                                               reinterpret_cast<const uint32_t *>(&LB[boff / 4]));
+                                        n_lines += probe_block(q[l], x0, y0, pb, reinterpret_cast<const uint8_t *>(T.data()), reinterpret_cast<const uint8_t *>(TT.data()),
+                                                           reinterpret_cast<const uint8_t *>(LB.data()), (uint32_t)(boff * 4));
                                         ++n_probes;
                                     }
                                 }
@@ -544,7 +544,8 @@ extern "C" int list_emulate(const uint32_t *cx, const uint32_t *cy, const uint8_
                             return;
                         }
                         const size_t boff = ((size_t)t.by * P.bw + t.bx) * 64;
-                        probe_block(tq, x0, y0, pb, &P.T[boff], &P.TT[boff], reinterpret_cast<const uint32_t *>(&P.LB[boff / 4]));
+                        probe_block(tq, x0, y0, pb, reinterpret_cast<const uint8_t *>(P.T.data()), reinterpret_cast<const uint8_t *>(P.TT.data()),
+                                    reinterpret_cast<const uint8_t *>(P.LB.data()), (uint32_t)(boff * 4));
                         ++n_probes;
                     }
                     res[i] = tq;
