@@ -157,12 +157,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void sa
         auto dword_at = [](const uint8_t *base, uint32_t off) __attribute__((always_inline)) -> uint32_t {
             return *reinterpret_cast<const uint32_t *>(base + off);
         };
+        // the row pointers step from row to row (one scalar add each where the clamp lets the row
+        // advance) instead of being multiplied out afresh: the scalar unit is the busiest one here
+        int yy_cur = min(max(ys - RAD, 0), hmax);
+        const uint8_t *la = limg + (size_t)yy_cur * a.lstride, *ra = rimg + (size_t)yy_cur * a.rstride;
         auto fetch = [&](int t) __attribute__((always_inline)) {
-            const int yy = min(max(ys - RAD + t, 0), hmax); // uniform
-            const uint8_t *la = limg + (size_t)yy * a.lstride, *ra = rimg + (size_t)yy * a.rstride;
+            const int yy = min(max(ys - RAD + t, 0), hmax); // uniform; yy_cur or yy_cur + 1
+            if (yy != yy_cur) {
+                la += a.lstride;
+                ra += a.rstride;
+                yy_cur = yy;
+            }
             if (!same_m)
                 set_m((uint32_t)reinterpret_cast<uintptr_t>(la) & 3u, (uint32_t)reinterpret_cast<uintptr_t>(ra) & 3u);
-            const uint8_t *lq = la - m_l, *rq = ra - m_r; // aligned, uniform
+            const uint8_t *lq = la - m_l, *rq = ra - m_r; // aligned, uniform (as `la & ~3` the loads lose their scalar base: + 10 %)
             pl0 = dword_at(lq, i0_l);
             pl1 = dword_at(lq, i1_l);
             pr0 = dword_at(rq, i0_r);
