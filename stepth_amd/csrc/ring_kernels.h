@@ -308,14 +308,14 @@ __global__ __launch_bounds__(256) void paint_1x1_vec4_kernel(PaintArgs a)
     build_lut(lut, a.max_word + f, a.identity, a.max_out ? a.max_out + f : nullptr);
     const uint8_t *raw = a.raw + (size_t)f * a.raw_stride;
     uint8_t *out = a.out[f];
-    const uint32_t rows = a.row_end - a.row_begin, w4 = a.w >> 2;
-    const size_t total = (size_t)rows * w4;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (size_t)gridDim.x * blockDim.x) {
-        const uint32_t r = (uint32_t)(i / w4), c = (uint32_t)(i % w4);
-        if (!a.rp.owns(a.row_begin + r))
+    // a workgroup takes (row, run of 256 dwords) items: the row of an item is worked out once per
+    // workgroup, not per thread (a 64-bit division per dword used to be most of this kernel)
+    const uint32_t rows = a.row_end - a.row_begin, w4 = a.w >> 2, runs = (w4 + 255u) >> 8;
+    for (uint32_t item = blockIdx.x; item < rows * runs; item += gridDim.x) {
+        const uint32_t r = item / runs, c = (item - r * runs) * 256u + threadIdx.x; // uniform r
+        if (c >= w4 || !a.rp.owns(a.row_begin + r))
             continue;
-        const uint32_t v = reinterpret_cast<const uint32_t *>(raw)[i];
+        const uint32_t v = reinterpret_cast<const uint32_t *>(raw)[(size_t)r * w4 + c];
         const uint32_t o = (uint32_t)lut[v & 0xff] | ((uint32_t)lut[(v >> 8) & 0xff] << 8) |
                            ((uint32_t)lut[(v >> 16) & 0xff] << 16) |
                            ((uint32_t)lut[v >> 24] << 24);
