@@ -665,10 +665,17 @@ __global__ __launch_bounds__(1024) void tile_cost_kernel(TileArgs a, TileOrderBu
             const uint8_t v[3] = {p[0], p[1], p[2]};
             uint32_t lo, hi;
             make_box(v, a.prec, lo, hi);
-            bool near = false;
+            // a full match is the numerically largest value r = (max+lo) & ~(min+hi) & guard can take
+            // (tile_lane.h LineTest::any): "some block's bounds meet the box" = max(r) == guard --
+            // one 64-bit add, one v_bitop3 and half a v_max3 per block
+            const uint64_t kq = ((uint64_t)hi << 32) | lo;
+            uint32_t rmax = 0;
 #pragma unroll 7
-            for (int e = 0; e < 49; ++e)
-                near |= box_meets(s_win[tl][e].x, s_win[tl][e].y, lo, hi);
+            for (int e = 0; e < 49; ++e) {
+                const uint64_t t = (((uint64_t)s_win[tl][e].y << 32) | s_win[tl][e].x) + kq;
+                rmax = max(rmax, (uint32_t)t & ~(uint32_t)(t >> 32) & kGuard);
+            }
+            const bool near = rmax == kGuard;
             if (!near && a.max_steps <= 160u) {
                 w = 4u; // a short reach: how far matters little next to how many (measured)
             } else if (!near) {
