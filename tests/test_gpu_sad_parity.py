@@ -42,6 +42,34 @@ def test_sad_rgba_left_and_strips(engine, oracle):
     np.testing.assert_array_equal(out, ref)
 
 
+def test_sad_device_images_at_any_alignment(engine, oracle):
+    """the search fetches each pixel as the aligned dword pair around its three bytes (csrc/
+    sad_kernels.h): device images whose first byte sits at every offset inside a dword, row
+    pitches that are not multiples of 4 (the offsets then change from row to row), an RGBA main
+    image, widths below a wave and below a dword -- each a view that ends where its buffer ends"""
+    import torch
+    from stepth_amd import MODE_SAD_WINDOW, synth
+    rng = np.random.default_rng(11)
+
+    def view(a, off):  # a device view at byte offset `off` of a buffer that ends with it
+        b = torch.zeros(a.size + off, dtype=torch.uint8, device="cuda")
+        v = b[off:].view(*a.shape)
+        v.copy_(torch.from_numpy(a))
+        return v
+
+    for w, h, d_max, win in ((150, 33, 40, 5), (131, 20, 24, 9), (67, 19, 16, 3), (5, 7, 6, 5), (1, 9, 4, 3)):
+        l, r, _ = synth.stereo_pair(max(w, 8), h, min(d_max, 16), seed=w)
+        l, r = np.ascontiguousarray(l[:, :w]), np.ascontiguousarray(r[:, :w])
+        want = oracle.sad_rows(l, r, d_max, win, [5, 5, 5])
+        for off_l in range(4):
+            off_r = (off_l * 3 + 1) & 3
+            lm = np.concatenate([l, rng.integers(0, 256, (h, w, 1), dtype=np.uint8)], axis=2) if off_l & 1 else l
+            outs, mx = engine.depth_from_additional_batch([view(lm, off_l)], [view(r, off_r)], [5, 5, 5],
+                                                          mode=MODE_SAD_WINDOW, d_max=d_max, win=win, raw_only=True)
+            np.testing.assert_array_equal(outs[0].cpu().numpy(), want, err_msg=f"{w}x{h} offsets {off_l},{off_r}")
+            assert list(mx) == [int(want.max())]
+
+
 def test_sad_larger_frame_band_and_planted_disparity(engine, oracle):
     from stepth_amd import synth
     l, r, disp = synth.stereo_pair(640, 360, 64, seed=2)
