@@ -166,8 +166,10 @@ int guard_other(stepth_engine *e, const char *what) noexcept
     } while (0)
 
 // Brings a caller image onto the device if it is host memory.  Returns the device view.
+// (r0, r1, cols: the rectangle of a host image that travels -- rows [r0, r1), columns [0, cols);
+// the staged copy keeps the full geometry, what lies outside the rectangle is never read)
 int to_device(stepth_engine *e, const stepth_image &im, DevBuf &stage, const uint8_t *&dptr,
-              size_t &dstride)
+              size_t &dstride, uint32_t r0 = 0, uint32_t r1 = 0xFFFFFFFFu, uint32_t cols = 0xFFFFFFFFu)
 {
     const size_t row = (size_t)im.width * im.channels;
     if (im.memory == STEPTH_MEM_DEVICE) {
@@ -177,8 +179,13 @@ int to_device(stepth_engine *e, const stepth_image &im, DevBuf &stage, const uin
     }
     const size_t pitch = (row + 15) & ~(size_t)15;
     TRY(reserve(e, stage, pitch * im.height));
-    HIP_TRY(e, hipMemcpy2DAsync(stage.p, pitch, im.data, im.stride, row, im.height,
-                                hipMemcpyHostToDevice, e->stream));
+    r1 = std::min(r1, im.height);
+    r0 = std::min(r0, r1);
+    cols = std::min(cols, im.width);
+    if (r1 > r0 && cols)
+        HIP_TRY(e, hipMemcpy2DAsync(static_cast<uint8_t *>(stage.p) + (size_t)r0 * pitch, pitch,
+                                    static_cast<const uint8_t *>(im.data) + (size_t)r0 * im.stride, im.stride,
+                                    (size_t)cols * im.channels, r1 - r0, hipMemcpyHostToDevice, e->stream));
     dptr = static_cast<const uint8_t *>(stage.p);
     dstride = pitch;
     return STEPTH_OK;
@@ -1049,7 +1056,18 @@ int stepth_depth_from_additional(stepth_engine *e, const stepth_image *main_im,
     const uint8_t *d_main = nullptr, *d_add = nullptr;
     size_t ms = 0, as = 0;
     TRY(to_device(e, *main_im, e->stage_main, d_main, ms));
-    TRY(to_device(e, *add_im, e->stage_add, d_add, as));
+    {
+        // ring mode without a caller's group list reads the additional image only where a search
+        // can reach (see batch_host): the rest of a host image does not travel
+        uint32_t ar0 = 0, ar1 = 0xFFFFFFFFu, ac1 = 0xFFFFFFFFu;
+        if (p.mode == STEPTH_MODE_RING_FIRST_HIT && !groups && p.max_steps < 0x40000000u && p.tile_w && p.tile_h) {
+            const uint32_t reach = p.max_steps ? p.max_steps - 1u : 0u, c_lo = row0 / 2u;
+            ar0 = (c_lo > reach ? c_lo - reach : 0u) & ~7u;
+            ar1 = (uint32_t)std::min<uint64_t>(0xFFFFFFF8ull, ((uint64_t)(row1 + std::min(p.tile_h, H)) / 2u + reach + 1u + 7u) & ~(uint64_t)7);
+            ac1 = (uint32_t)std::min<uint64_t>(0xFFFFFFF8ull, ((uint64_t)(W + std::min(p.tile_w, W)) / 2u + reach + 1u + 7u) & ~(uint64_t)7);
+        }
+        TRY(to_device(e, *add_im, e->stage_add, d_add, as, ar0, ar1, ac1));
+    }
 
     uint8_t *d_out = nullptr;
     size_t os = 0;
@@ -1653,6 +1671,20 @@ static int batch_host(stepth_engine *e, uint32_t n_frames, const stepth_image *m
     if (row0 >= row1 || row1 > H)
         return fail(e, STEPTH_ERR_BAD_ARG, "row strip [%u,%u) outside 0..%u", row0, row1, H);
     const bool pattern = p.row_block != 0;
+    // Ring mode reads the additional image only where a search can reach: centres lie at half the
+    // main image's coordinates (middle = ((x + w) / 2, (y + h) / 2), src/depth_image.rs:114-117),
+    // so rows beyond (row1 + tile_h) / 2 + reach and columns beyond (W + tile_w) / 2 + reach -- two
+    // thirds of a 1080p frame at reach 127 -- never travel.  (Block-aligned, the pack kernels' own
+    // rectangle: what lies outside it in the staging buffer is an earlier frame's and, like the
+    // unpacked blocks, beyond every query's limit.)
+    uint32_t ar0 = 0, ar1 = Ha, ac1 = Wa;
+    if (p.mode == STEPTH_MODE_RING_FIRST_HIT && p.max_steps < 0x40000000u && p.tile_w && p.tile_h) {
+        const uint32_t reach = p.max_steps ? p.max_steps - 1u : 0u, c_lo = row0 / 2u;
+        ar0 = std::min((c_lo > reach ? c_lo - reach : 0u) & ~7u, Ha);
+        ar1 = (uint32_t)std::min<uint64_t>(Ha, ((uint64_t)(row1 + std::min(p.tile_h, H)) / 2u + reach + 1u + 7u) & ~(uint64_t)7);
+        ac1 = (uint32_t)std::min<uint64_t>(Wa, ((uint64_t)(W + std::min(p.tile_w, W)) / 2u + reach + 1u + 7u) & ~(uint64_t)7);
+        ar1 = std::max(ar1, ar0);
+    }
 
     auto download = [&](uint32_t k) -> int { // chunk k's depth rows -> caller memory
         const uint32_t s = k & 1u, f0 = chunks[k].first, nf = chunks[k].second;
@@ -1681,8 +1713,11 @@ static int batch_host(stepth_engine *e, uint32_t n_frames, const stepth_image *m
             uint8_t *a = static_cast<uint8_t *>(e->pipe_add[s].p) + abytes * f;
             HIP_TRY(e, hipMemcpy2DAsync(m, mpitch, mains[f0 + f].data, mains[f0 + f].stride, (size_t)W * mch,
                                         H, hipMemcpyHostToDevice, e->copy_in));
-            HIP_TRY(e, hipMemcpy2DAsync(a, apitch, adds[f0 + f].data, adds[f0 + f].stride, (size_t)Wa * 3, Ha,
-                                        hipMemcpyHostToDevice, e->copy_in));
+            if (ar1 > ar0 && ac1)
+                HIP_TRY(e, hipMemcpy2DAsync(a + (size_t)ar0 * apitch, apitch,
+                                            static_cast<const uint8_t *>(adds[f0 + f].data) + (size_t)ar0 * adds[f0 + f].stride,
+                                            adds[f0 + f].stride, (size_t)ac1 * 3, ar1 - ar0, hipMemcpyHostToDevice,
+                                            e->copy_in));
             dm[f] = stepth_image{m, W, H, mch, STEPTH_MEM_DEVICE, mpitch};
             da[f] = stepth_image{a, Wa, Ha, 3, STEPTH_MEM_DEVICE, apitch};
             dd[f] = stepth_image{static_cast<uint8_t *>(e->pipe_out[s].p) + obytes * f, W, H, 1,
