@@ -1055,7 +1055,10 @@ int stepth_depth_from_additional(stepth_engine *e, const stepth_image *main_im,
 
     const uint8_t *d_main = nullptr, *d_add = nullptr;
     size_t ms = 0, as = 0;
-    TRY(to_device(e, *main_im, e->stage_main, d_main, ms));
+    if (p.mode == STEPTH_MODE_RING_FIRST_HIT && !groups) // (rows of the strip only; a caller's groups may lie anywhere)
+        TRY(to_device(e, *main_im, e->stage_main, d_main, ms, row0, row1));
+    else
+        TRY(to_device(e, *main_im, e->stage_main, d_main, ms));
     {
         // ring mode without a caller's group list reads the additional image only where a search
         // can reach (see batch_host): the rest of a host image does not travel
@@ -1711,8 +1714,11 @@ static int batch_host(stepth_engine *e, uint32_t n_frames, const stepth_image *m
         for (uint32_t f = 0; f < nf; ++f) {
             uint8_t *m = static_cast<uint8_t *>(e->pipe_main[s].p) + mbytes * f;
             uint8_t *a = static_cast<uint8_t *>(e->pipe_add[s].p) + abytes * f;
-            HIP_TRY(e, hipMemcpy2DAsync(m, mpitch, mains[f0 + f].data, mains[f0 + f].stride, (size_t)W * mch,
-                                        H, hipMemcpyHostToDevice, e->copy_in));
+            // (ring mode reads the main image's rows of the strip only; the SAD window reaches beyond them)
+            const uint32_t mr0 = p.mode == STEPTH_MODE_RING_FIRST_HIT ? row0 : 0u, mr1 = p.mode == STEPTH_MODE_RING_FIRST_HIT ? row1 : H;
+            HIP_TRY(e, hipMemcpy2DAsync(m + (size_t)mr0 * mpitch, mpitch,
+                                        static_cast<const uint8_t *>(mains[f0 + f].data) + (size_t)mr0 * mains[f0 + f].stride,
+                                        mains[f0 + f].stride, (size_t)W * mch, mr1 - mr0, hipMemcpyHostToDevice, e->copy_in));
             if (ar1 > ar0 && ac1)
                 HIP_TRY(e, hipMemcpy2DAsync(a + (size_t)ar0 * apitch, apitch,
                                             static_cast<const uint8_t *>(adds[f0 + f].data) + (size_t)ar0 * adds[f0 + f].stride,
