@@ -748,8 +748,9 @@ def main():
                 "value_pageable": round(n_host * W * H / t_page / 1e6, 1),
                 "value_page_locked": round(n_host * W * H / t_pin / 1e6, 1), "unit": "Mpixels/s",
                 "workload": f"{n_host} host-resident 1920x1080 pairs through the pipelined host batch: "
-                            "H2D of both images, kernels, D2H of the depth map (14.5 MB per frame "
-                            "over PCIe)", "matches_device_path": bool(e2e_ok)}
+                            "H2D of the main image and of the third of the additional one a search can "
+                            "reach, kernels, D2H of the depth map (10.5 of a frame's 14.5 MB travel)",
+                "matches_device_path": bool(e2e_ok)}
             del pm, pa, po, hm, ha, ho
             eng.use_torch_stream()
             # -- the engine's second mode on the same frames (north_star's literal windowed SAD;
